@@ -1,0 +1,683 @@
+"""CPU ORACLE -- test infrastructure, NOT product code.
+
+A NumPy restatement of the planar-flow hot path of huzjkevin/planar_optical_flow
+(SURVEY.md section 8(a), rows A1-A16).  Only ``tests/``, ``__graft_entry__.smoke()``
+and the ``cpu_baseline`` leg of ``bench.py`` may import this module; the shipped
+package ``planar_optical_flow_amd`` never does (it fails loudly when the HIP
+library is missing).
+
+Parity status: PINNED.  Every function below is checked in
+``tests/test_oracle_golden.py`` against fixtures under ``tests/golden/`` that were
+produced by importing the reference itself in the build container
+(``tools/gen_golden.py``).  Two rows have no runnable reference counterpart and are
+pinned differently (see their docstrings): A13 (segment features; reference module
+is not importable) and A16 (rotated IoU; numba.cuda kernel, pinned by the
+reference's own ``__main__`` known answer plus analytic cases).
+
+All ``file:line`` citations are relative to the reference checkout.
+"""
+import math
+
+import numpy as np
+
+# --------------------------------------------------------------------------
+# A1  laser angle grid                         src/utils/utils.py:25-29
+# --------------------------------------------------------------------------
+
+
+def laser_phi(angle_inc=np.radians(0.5), num_pts=450):
+    """fov=(num_pts-1)*angle_inc; linspace(-fov/2, +fov/2, num_pts), float64."""
+    fov = (num_pts - 1) * angle_inc
+    return np.linspace(-0.5 * fov, 0.5 * fov, num_pts)
+
+
+# --------------------------------------------------------------------------
+# A2  polar <-> cartesian                       src/utils/utils.py:32-48
+# --------------------------------------------------------------------------
+
+
+def polar_to_xy(r, phi):
+    """x = r cos(phi), y = r sin(phi).  float32 ranges promote to float64."""
+    return r * np.cos(phi), r * np.sin(phi)
+
+
+def xy_to_polar(x, y):
+    """src/utils/utils.py:39-43."""
+    return np.hypot(x, y), np.arctan2(y, x)
+
+
+# --------------------------------------------------------------------------
+# A3  rigid-motion flow targets
+# --------------------------------------------------------------------------
+
+
+def _rot2_f32(phi):
+    """src/utils/utils.py:601-606 (2-D branch): the matrix is stored in float32."""
+    c, s = np.cos(phi), np.sin(phi)
+    return np.array([[c, -s], [s, c]], dtype=np.float32)
+
+
+def displacement_from_odometry(xy1, odom0, odom1):
+    """A3, src/utils/utils.py:639-662.
+
+    disp = xy1 (I - R0^T R1)^T - (R0^T (t1 - t0))^T with R0, R1 float32.
+    """
+    r0 = _rot2_f32(odom0[2])
+    r1 = _rot2_f32(odom1[2])
+    m = np.eye(2) - np.matmul(r0.T, r1)
+    dt = (odom1[:2] - odom0[:2]).reshape(2, 1)
+    return np.matmul(xy1, m.T) - np.matmul(r0.T, dt).reshape(1, 2)
+
+
+def flow_target(scan, phi, odom0, odom1, to_canonical=False):
+    """A3a, src/utils/utils.py:204-229 (all float64 matrices)."""
+    s0, c0 = np.sin(odom0[-1]), np.cos(odom0[-1])
+    w2f = np.array([[c0, -s0], [s0, c0]])
+    dphi = odom1[-1] - odom0[-1]
+    s1, c1 = np.sin(dphi), np.cos(dphi)
+    f2f = np.array([[c1, -s1], [s1, c1]])
+    t0 = np.matmul(odom1[:2] - odom0[:2], w2f.T)
+    xy0 = np.array(polar_to_xy(scan, phi)).T
+    xy1 = np.matmul(xy0, f2f.T) - t0
+    flow = xy1 - xy0
+    if to_canonical:
+        flow = flow_to_canonical(flow, phi)
+    return flow
+
+
+def velocity_from_odometry(xy1, odom0, odom1):
+    """A3b, src/utils/utils.py:609-636 (float32 rotation and cross matrices)."""
+    d = odom1 - odom0
+    r1 = _rot2_f32(odom1[2])
+    lin = np.matmul(r1.T, d[:2].reshape(2, 1))
+    cross = d[2] * np.array([[0, -1], [1, 0]], dtype=np.float32)
+    return -lin.reshape(1, 2) - np.matmul(xy1, cross.T)
+
+
+def prepared_flow_target(scan, phi, odom_t, odom):
+    """A3c, bin/data_prepare.py:29-47: (v + w x r) * dt with reg 1e-6."""
+    reg = 1e-6
+    v = odom[:2] / (odom_t + reg)
+    w = np.asarray([0, 0, odom[-1] / (odom_t + reg)])
+    xy = np.array(polar_to_xy(scan, phi)).T
+    p3 = np.hstack([xy, np.zeros((len(xy), 1))])
+    return (np.cross(w, p3)[:, :2] + v) * odom_t
+
+
+def align_next_scan(scan_next, phi, odom, scan_dir):
+    """A3c (second half), src/utils/dataset.py:76-93: next scan rotated by the
+    odometry delta into the current frame (float32 matrices)."""
+    xy_next = np.stack(polar_to_xy(scan_next, phi), axis=1)
+    rot = np.array(
+        [[np.cos(odom[-1]), np.sin(odom[-1])], [-np.sin(odom[-1]), np.cos(odom[-1])]],
+        dtype=np.float32,
+    )
+    rot_t = np.array(
+        [[np.cos(scan_dir), -np.sin(scan_dir)], [np.sin(scan_dir), np.cos(scan_dir)]],
+        dtype=np.float32,
+    )
+    trans = np.matmul(odom[:-1], rot_t.T)
+    return np.matmul(xy_next, rot.T) + trans
+
+
+# --------------------------------------------------------------------------
+# A4  canonical <-> global flow frames         src/utils/utils.py:62-105
+# --------------------------------------------------------------------------
+
+
+def flow_to_canonical(flow, phi):
+    """Per-point rotation [[c,-s],[s,c]] applied to the flow vector (:62-75)."""
+    c, s = np.cos(phi), np.sin(phi)
+    out = np.empty_like(np.asarray(flow, dtype=np.result_type(flow, phi)))
+    out[:, 0] = c * flow[:, 0] + (-s) * flow[:, 1]
+    out[:, 1] = s * flow[:, 0] + c * flow[:, 1]
+    return out
+
+
+def flow_to_global(flow_c, phi):
+    """Inverse rotation [[c,s],[-s,c]] (:78-89; torch twin :92-105 in float32)."""
+    c, s = np.cos(phi), np.sin(phi)
+    out = np.empty_like(np.asarray(flow_c, dtype=np.result_type(flow_c, phi)))
+    out[:, 0] = c * flow_c[:, 0] + s * flow_c[:, 1]
+    out[:, 1] = (-s) * flow_c[:, 0] + c * flow_c[:, 1]
+    return out
+
+
+# --------------------------------------------------------------------------
+# A5  detection <-> canonical point frame       src/utils/utils.py:55-59,109-126
+# --------------------------------------------------------------------------
+
+
+def det_to_canonical(r, phi, det_r, det_phi):
+    dx = np.sin(det_phi - phi) * det_r
+    dy = np.cos(det_phi - phi) * det_r - r
+    return dx, dy
+
+
+def canonical_to_det(r, phi, dx, dy):
+    ty = r + dy
+    tphi = np.arctan2(dx, ty)
+    return ty / np.cos(tphi), tphi + phi
+
+
+# --------------------------------------------------------------------------
+# A6  association                              src/utils/utils.py:147-185,232-256
+# --------------------------------------------------------------------------
+
+
+def closest_detection(scan, phi, dets, radii):
+    """1-based index of the nearest detection whose disc contains the point,
+    0 when none does; first-minimum ties (np.argmin)."""
+    if len(dets) == 0:
+        return np.zeros_like(scan, dtype=int)
+    assert len(dets) == len(radii), "Need to give a radius for each detection!"
+    px, py = polar_to_xy(scan, phi)
+    d = np.empty((len(scan), len(dets) + 1))
+    d[:, 0] = 0.0
+    for k, (dr, dphi) in enumerate(dets):
+        cx, cy = polar_to_xy(dr, dphi)
+        # scipy cdist(euclidean) == sqrt(dx^2 + dy^2) in float64 for 2-D points
+        d[:, k + 1] = np.sqrt((px - cx) ** 2 + (py - cy) ** 2) - radii[k]
+    return np.argmin(d, axis=1)
+
+
+def regression_target(
+    scan, phi, wcs, was, wps,
+    radius_wc=0.6, radius_wa=0.4, radius_wp=0.35,
+    label_wc=1, label_wa=2, label_wp=3, pedestrian_only=False,
+):
+    """src/utils/utils.py:147-185 -> (target_cls int64 [N], target_reg float32 [N,2])."""
+    n = len(scan)
+    cls = np.zeros(n, dtype=np.int64)
+    reg = np.zeros((n, 2), dtype=np.float32)
+    if pedestrian_only:
+        dets = list(wps)
+        radii = [radius_wp] * len(wps)
+        labels = [0] + [1] * len(wps)
+    else:
+        dets = list(wcs) + list(was) + list(wps)
+        radii = [radius_wc] * len(wcs) + [radius_wa] * len(was) + [radius_wp] * len(wps)
+        labels = [0] + [label_wc] * len(wcs) + [label_wa] * len(was) + [label_wp] * len(wps)
+    idx = closest_detection(scan, phi, dets, radii)
+    hit = idx > 0
+    if np.any(hit):
+        darr = np.asarray(dets, dtype=np.float64).reshape(-1, 2)
+        sel = idx[hit] - 1
+        cls[hit] = np.asarray(labels, dtype=np.int64)[idx[hit]]
+        # the reference evaluates this per point with python scalars: float32
+        # range, float64 phi / detection
+        dx, dy = det_to_canonical(scan[hit], phi[hit], darr[sel, 0], darr[sel, 1])
+        reg[hit, 0] = dx
+        reg[hit, 1] = dy
+    return cls, reg
+
+
+# --------------------------------------------------------------------------
+# A7  masks                             src/utils/dataset_dr_spaam.py:511-529
+# --------------------------------------------------------------------------
+
+
+def dynamic_mask(xy, wcs, was, wps, radius_wc=2.5, radius_wa=2.0, radius_wp=2.0):
+    """0 where a point lies within `radius` of any detection centre, else 1 (float64)."""
+    n = xy.shape[0]
+    mask = np.ones(n, dtype=np.float64)
+    dets = list(wcs) + list(was) + list(wps)
+    radii = [radius_wc] * len(wcs) + [radius_wa] * len(was) + [radius_wp] * len(wps)
+    for (dr, dphi), rad in zip(dets, radii):
+        c = np.hstack(polar_to_xy(dr, dphi))
+        dist = np.linalg.norm(xy - c, axis=-1)
+        mask[dist <= rad] = 0.0
+    return mask
+
+
+def valid_point_mask(scan):
+    """Hard-coded 20 m threshold (:525-529); dtype follows the scan."""
+    m = np.ones_like(scan)
+    m[scan >= 20.0] = 0.0
+    return m
+
+
+# --------------------------------------------------------------------------
+# A8  cutout resampler                           src/utils/utils.py:259-334
+# --------------------------------------------------------------------------
+
+
+def atan_f32(x, mode="numpy"):
+    """half-angle arctangent of a float32 array.
+
+    mode="numpy": np.arctan on float32, i.e. what the reference executes.  Its
+        last bit depends on the CPU's SIMD dispatch (SVML on AVX-512, libm
+        otherwise): the reference itself is not bit-reproducible across hosts.
+    mode="cr": correctly rounded float32 arctangent (float64 arctan, rounded
+        once).  This is the definition the HIP kernel implements and the one the
+        bit-exact index tests use.
+    """
+    if mode == "numpy":
+        return np.arctan(x)
+    return np.arctan(x.astype(np.float64)).astype(np.float32)
+
+
+def cutout(
+    scans, phi, stride=1, centered=True, fixed=False, window_width=1.66,
+    window_depth=1.0, num_cutout_pts=48, padding_val=29.99, area_mode=False,
+    atan_mode="numpy", return_debug=False,
+):
+    """(T,N) float32 ranges -> (N/stride, T, P) float32 cutouts.
+
+    Follows src/utils/utils.py:259-334 operation by operation, including the
+    dtype of every intermediate (float32 half-angle, float64 index math,
+    float32 area-mode mean).
+    """
+    scans = np.asarray(scans)
+    T, N = scans.shape
+    P = num_cutout_pts
+    dists = scans[:, ::stride] if fixed else np.tile(scans[-1, ::stride], T).reshape(T, -1)
+    half = atan_f32(0.5 * window_width / np.maximum(dists, 1e-2), atan_mode)
+    step = 2.0 * half / (P - 1)
+    ang = phi[::stride] - half + np.arange(P).reshape(P, 1, 1) * step
+    idx = (ang - phi[0]) / (phi[1] - phi[0])
+    outbound = np.logical_or(idx < 0, idx > N - 1)
+    lo = np.clip(np.floor(idx), 0, N - 1).astype(np.int64)
+    hi = np.clip(lo + 1, 0, N - 1).astype(np.int64)
+    ratio = np.clip(idx - lo, 0.0, 1.0)
+    row = np.arange(T).reshape(1, T, 1) * N
+    flat = scans.reshape(-1)
+    v_lo = flat[lo + row]
+    v_hi = flat[hi + row]
+    ct = v_lo + ratio * (v_hi - v_lo)
+    dbg = {"lo": lo, "outbound": outbound}
+    if area_mode:
+        width = idx[-1] - idx[0]
+        amask = width > P
+        dbg["area_mask"] = amask
+        dbg["s_area"] = 0
+        if np.sum(amask) > 0:
+            s_area = int(math.ceil(np.max(width) / P))
+            dbg["s_area"] = s_area
+            PA = s_area * P
+            step_a = 2.0 * half / (PA - 1)
+            ang_a = phi[::stride] - half + np.arange(PA).reshape(PA, 1, 1) * step_a
+            idx_a = (ang_a - phi[0]) / (phi[1] - phi[0])
+            idx_a = np.rint(np.clip(idx_a, 0, N - 1)).astype(np.int32)
+            v_a = flat[idx_a + row]
+            v_a = v_a.reshape(P, s_area, T, dists.shape[1]).mean(axis=1)
+            ct[:, amask] = v_a[:, amask]
+    ct[outbound] = padding_val
+    ct = np.clip(ct, dists - window_depth, dists + window_depth)
+    if centered:
+        ct = ct - dists
+        ct = ct / window_depth
+    out = np.ascontiguousarray(ct.transpose((2, 1, 0)), dtype=np.float32)
+    if return_debug:
+        return out, dbg
+    return out
+
+
+# --------------------------------------------------------------------------
+# A11 greedy centre NMS                          src/utils/utils.py:535-571
+# --------------------------------------------------------------------------
+
+
+def nms_predicted_center(scan, phi, pred_cls, pred_reg, min_dist=0.5):
+    assert pred_cls.shape[1] == 1
+    r, p = canonical_to_det(scan, phi, pred_reg[:, 0], pred_reg[:, 1])
+    xs, ys = polar_to_xy(r, p)
+    order = np.argsort(pred_cls[:, 0])[::-1]
+    xs, ys = xs[order], ys[order]
+    scores = pred_cls[order]
+    n = len(scan)
+    dist = np.sqrt(np.square(xs.reshape(n, 1) - xs.reshape(1, n))
+                   + np.square(ys.reshape(n, 1) - ys.reshape(1, n)))
+    keep = np.ones(n, dtype=np.bool_)
+    inst = np.zeros(n, dtype=np.int32)
+    next_id = 1
+    for i in range(n):
+        if not keep[i]:
+            continue
+        dup = dist[i] < min_dist
+        keep[dup] = False
+        keep[i] = True
+        inst[order[dup]] = next_id
+        next_id += 1
+    return np.stack((xs, ys), axis=1)[keep], scores[keep], inst
+
+
+# --------------------------------------------------------------------------
+# A12 flow losses / metrics
+# --------------------------------------------------------------------------
+
+
+def epe_per_sample(pred, target):
+    """src/depracted/model/prototype.py:27-32 -> (loss, err_batch)."""
+    err = np.linalg.norm(pred - target, axis=-1).mean(axis=1)
+    return err.mean(), err
+
+
+def epe_masked(pred, target, mask=None):
+    """src/depracted/model/dr_spaam.py:22-27."""
+    e = np.linalg.norm(pred - target, axis=-1)
+    return e[mask == 1.0].mean() if mask is not None else e.mean()
+
+
+def epe_aae_eval(pred, target):
+    """src/utils/eval_utils.py:129-134; atan2 takes (x, y) in that order."""
+    epe = np.linalg.norm(pred - target, axis=-1).mean(axis=1)
+    aae = np.abs(np.arctan2(pred[..., 0], pred[..., 1])
+                 - np.arctan2(target[..., 0], target[..., 1])).mean(axis=1) * 180 / np.pi
+    return epe, aae
+
+
+# --------------------------------------------------------------------------
+# A9  banded patch correlation      src/depracted/model/prototype.py:118-156
+# --------------------------------------------------------------------------
+
+
+def band_correlation(f1, f2, kernel_size=3, max_displacement=5):
+    """(B,C,n) x2 -> (B, 2*maxd+1, n): dot product of the clamped 3-tap,
+    C-channel patch around i in f1 with the patch around clamp(i+d) in f2."""
+    B, C, n = f1.shape
+    hk = kernel_size // 2
+    taps = np.clip(np.arange(n)[:, None] + np.arange(-hk, hk + 1)[None, :], 0, n - 1)
+    p1 = f1[:, :, taps]                      # (B,C,n,k)
+    p2 = f2[:, :, taps]
+    j = np.clip(np.arange(n)[:, None] + np.arange(-max_displacement, max_displacement + 1)[None, :],
+                0, n - 1)                    # (n, D)
+    out = np.einsum("bcik,bcidk->bdi", p1, p2[:, :, j, :])
+    return out
+
+
+# --------------------------------------------------------------------------
+# A10 windowed spatial attention  src/depracted/model/dr_spaam.py:145-217
+# --------------------------------------------------------------------------
+
+
+def spatial_attention(emb_x, emb_t, x, tmpl, alpha=0.5, window_size=11):
+    """emb_* (B,N,E); x, tmpl (B,N,F) -> (out (B,N,F), band (B,N,w)).
+
+    band[i,k] = <emb_x[i], emb_t[clamp(i-hw+k)]> (duplicates kept);
+    softmax over the *distinct* in-window columns (the reference builds the
+    mask by scatter, so clamped duplicates collapse); out = a*x + (1-a)*P@tmpl.
+    """
+    B, N, _ = emb_x.shape
+    hw = int(window_size / 2)
+    cols = np.clip(np.arange(N)[:, None] + np.arange(-hw, hw + 1)[None, :], 0, N - 1)
+    sim = np.matmul(emb_x, emb_t.transpose(0, 2, 1))
+    band = np.take_along_axis(sim, np.broadcast_to(cols, (B,) + cols.shape), axis=2)
+    mask = np.zeros((N, N), dtype=sim.dtype)
+    mask[np.arange(N)[:, None], cols] = 1.0
+    s = sim - 1e10 * (1.0 - mask)
+    e = np.exp(s - s.max(axis=-1, keepdims=True)) * mask
+    p = e / e.sum(axis=-1, keepdims=True)
+    out = alpha * x + (1.0 - alpha) * np.matmul(p, tmpl)
+    return out, band
+
+
+# --------------------------------------------------------------------------
+# A13 jump-distance segments + per-segment least squares
+#     src/depracted/model/adaboost_person_det.py:71-90, 102-210
+# The reference module cannot be imported (broken import path, argv parsing at
+# import), so this row is restated from the text; the two solves are pinned by
+# np.linalg.pinv / sklearn LinearRegression in tests (tolerance, well
+# conditioned segments).
+# --------------------------------------------------------------------------
+
+
+def segment_cuts(scan, jump_dist=0.5):
+    """Indices where |r[i]-r[i-1]| >= jump_dist (:79)."""
+    return np.clip(np.where(np.abs(scan[1:] - scan[:-1]) >= jump_dist)[0] + 1, 0, len(scan) - 1)
+
+
+def fit_line(seg):
+    """Ordinary least squares y = k x + b (2x2 normal equations), :145-159.
+    Returns (k, b, residual) with residual = sum(x cos a + y sin a - r)."""
+    x, y = seg[:, 0], seg[:, 1]
+    A = np.stack([x, np.ones_like(x)], axis=1)
+    k, b = np.matmul(np.linalg.pinv(A), y)
+    nrm = np.sqrt(k * k + 1.0)
+    res = np.sum(x * (k / nrm) + y * (-1.0 / nrm) - np.abs(b / nrm))
+    return k, b, res
+
+
+def fit_circle(seg):
+    """Algebraic circle fit A=[-2x,-2y,1], rhs=-(x^2+y^2), X=pinv(A) rhs (:162-168).
+    Returns (xc, yc, rc, Sc)."""
+    n = len(seg)
+    A = np.hstack((-2.0 * seg, np.ones((n, 1))))
+    rhs = -np.square(seg[:, 0]) - np.square(seg[:, 1])
+    X = np.matmul(np.linalg.pinv(A), rhs)
+    rc = np.sqrt(X[0] ** 2 + X[1] ** 2 - X[2])
+    sc = np.sum(np.square(rc - np.sqrt(np.linalg.norm(X[:-1] - seg, axis=-1))))
+    return X[0], X[1], rc, sc
+
+
+def segment_features(scan, phi, jump_dist=0.5):
+    """Geometric features of every jump-distance segment of one scan.
+
+    Columns (the reference's order, :108-201, minus the data-set coupled
+    entries: median deviation uses a Frobenius norm there, mean speed needs the
+    next scan, label needs annotations):
+      0 n, 1 sigma, 2 jump_prev, 3 jump_next, 4 width, 5 line_residual,
+      6 circ_Sc, 7 radius, 8 boundary_len, 9 boundary_std, 10 sum_curvature,
+      11 mean_ang_diff, 12 line_k, 13 line_b, 14 xc, 15 yc
+    Segments with fewer than 3 points get NaN in the fit columns.
+    """
+    xy = np.array(polar_to_xy(scan, phi)).T
+    cuts = segment_cuts(scan, jump_dist)
+    segs = np.split(xy, cuts, axis=0)
+    S = len(segs)
+    out = np.full((S, 16), np.nan)
+    for i, seg in enumerate(segs):
+        n = len(seg)
+        out[i, 0] = n
+        mean = seg.mean(axis=0)
+        d = np.linalg.norm(seg - mean, axis=-1)
+        out[i, 1] = np.sqrt(np.sum(d * d)) / (n - 1) if n > 1 else np.nan
+        prev = segs[max(0, i - 1)]
+        nxt = segs[min(i + 1, S - 1)]
+        out[i, 2] = np.linalg.norm(prev[-1] - seg[0])
+        out[i, 3] = np.linalg.norm(seg[-1] - nxt[0])
+        out[i, 4] = np.linalg.norm(seg[-1] - seg[0])
+        if n >= 3:
+            k, b, res = fit_line(seg)
+            out[i, 5], out[i, 12], out[i, 13] = res, k, b
+            xc, yc, rc, sc = fit_circle(seg)
+            out[i, 6], out[i, 7], out[i, 14], out[i, 15] = sc, rc, xc, yc
+        e = np.linalg.norm(seg[1:] - seg[:-1], axis=-1)
+        out[i, 8] = e.sum()
+        out[i, 9] = e.std() if n > 1 else np.nan
+        if n >= 3:
+            a, b_, c = seg[:-2], seg[1:-1], seg[2:]
+            da = np.linalg.norm(b_ - a, axis=-1)
+            db = np.linalg.norm(c - b_, axis=-1)
+            dc = np.linalg.norm(a - c, axis=-1)
+            area = np.abs(0.5 * (a[:, 0] * (b_[:, 1] - c[:, 1]) + b_[:, 0] * (c[:, 1] - a[:, 1])
+                                 + c[:, 0] * (a[:, 1] - b_[:, 1])))
+            out[i, 10] = np.sum(4 * area / (da * db * dc))
+            ba, bc = a - b_, c - b_
+            cosv = np.einsum("ij,ij->i", ba, bc) / (np.linalg.norm(ba, axis=-1) * np.linalg.norm(bc, axis=-1))
+            out[i, 11] = np.mean(np.arccos(cosv))
+    return cuts, out
+
+
+# --------------------------------------------------------------------------
+# A14 box-head feeder                        box_regressor.py:43-105
+# --------------------------------------------------------------------------
+
+
+def radius_query(points, center, radius=0.4):
+    """box_regressor.py:94-105."""
+    return points[np.linalg.norm(points - center, axis=1) <= radius]
+
+
+def resample_fixed(seg, size, rng):
+    """box_regressor.py:61-70 with the RNG injected (reference uses the global
+    np.random state): >size -> random subset, else repeat + pad + shuffle."""
+    seg = seg.copy()
+    if len(seg) > size:
+        rng.shuffle(seg)
+        return seg[:size]
+    rep, pad = size // len(seg), size % len(seg)
+    rng.shuffle(seg)
+    seg = np.repeat(seg, rep, axis=0)
+    seg = np.vstack((seg, seg[:pad]))
+    rng.shuffle(seg)
+    return seg
+
+
+# --------------------------------------------------------------------------
+# A16 rotated-box IoU (float32)          src/utils/rotate_iou.py:20-404
+# --------------------------------------------------------------------------
+
+_f = np.float32
+
+
+def _corners(b):
+    """:210-231; clockwise corners rotated clockwise by the angle."""
+    ang = b[4]
+    c, s = _f(math.cos(ang)), _f(math.sin(ang))
+    hx, hy = _f(b[2] / _f(2)), _f(b[3] / _f(2))
+    xs = [-hx, -hx, hx, hx]
+    ys = [-hy, hy, hy, -hy]
+    out = np.empty(8, dtype=np.float32)
+    for i in range(4):
+        out[2 * i] = _f(_f(_f(c * xs[i]) + _f(s * ys[i])) + b[0])
+        out[2 * i + 1] = _f(_f(_f(-s * xs[i]) + _f(c * ys[i])) + b[1])
+    return out
+
+
+def _inside(px, py, q):
+    """:168-184."""
+    ab0, ab1 = _f(q[2] - q[0]), _f(q[3] - q[1])
+    ad0, ad1 = _f(q[6] - q[0]), _f(q[7] - q[1])
+    ap0, ap1 = _f(px - q[0]), _f(py - q[1])
+    abab = _f(_f(ab0 * ab0) + _f(ab1 * ab1))
+    abap = _f(_f(ab0 * ap0) + _f(ab1 * ap1))
+    adad = _f(_f(ad0 * ad0) + _f(ad1 * ad1))
+    adap = _f(_f(ad0 * ap0) + _f(ad1 * ap1))
+    return abab >= abap and abap >= 0 and adad >= adap and adap >= 0
+
+
+def _edge_hit(p1, p2, i, j):
+    """:81-122."""
+    A = (p1[2 * i], p1[2 * i + 1])
+    B = (p1[2 * ((i + 1) % 4)], p1[2 * ((i + 1) % 4) + 1])
+    C = (p2[2 * j], p2[2 * j + 1])
+    D = (p2[2 * ((j + 1) % 4)], p2[2 * ((j + 1) % 4) + 1])
+    BA0, BA1 = _f(B[0] - A[0]), _f(B[1] - A[1])
+    DA0, CA0 = _f(D[0] - A[0]), _f(C[0] - A[0])
+    DA1, CA1 = _f(D[1] - A[1]), _f(C[1] - A[1])
+    acd = _f(DA1 * CA0) > _f(CA1 * DA0)
+    bcd = _f(_f(D[1] - B[1]) * _f(C[0] - B[0])) > _f(_f(C[1] - B[1]) * _f(D[0] - B[0]))
+    if acd != bcd:
+        abc = _f(CA1 * BA0) > _f(BA1 * CA0)
+        abd = _f(DA1 * BA0) > _f(BA1 * DA0)
+        if abc != abd:
+            DC0, DC1 = _f(D[0] - C[0]), _f(D[1] - C[1])
+            ABBA = _f(_f(A[0] * B[1]) - _f(B[0] * A[1]))
+            CDDC = _f(_f(C[0] * D[1]) - _f(D[0] * C[1]))
+            DH = _f(_f(BA1 * DC0) - _f(BA0 * DC1))
+            Dx = _f(_f(ABBA * DC0) - _f(BA0 * CDDC))
+            Dy = _f(_f(ABBA * DC1) - _f(BA1 * CDDC))
+            return _f(Dx / DH), _f(Dy / DH)
+    return None
+
+
+def _poly_area_sorted(pts, n):
+    """sort_vertex_in_convex_polygon (:39-78) then fan area (:26-36)."""
+    if n > 0:
+        cx = _f(0)
+        cy = _f(0)
+        for i in range(n):
+            cx = _f(cx + pts[2 * i])
+            cy = _f(cy + pts[2 * i + 1])
+        cx, cy = _f(cx / _f(n)), _f(cy / _f(n))
+        vs = np.zeros(16, dtype=np.float32)
+        for i in range(n):
+            vx, vy = _f(pts[2 * i] - cx), _f(pts[2 * i + 1] - cy)
+            d = _f(math.sqrt(_f(_f(vx * vx) + _f(vy * vy))))
+            vx, vy = _f(vx / d), _f(vy / d)
+            if vy < 0:
+                vx = _f(_f(-2) - vx)
+            vs[i] = vx
+        for i in range(1, n):
+            if vs[i - 1] > vs[i]:
+                t, tx, ty = vs[i], pts[2 * i], pts[2 * i + 1]
+                j = i
+                while j > 0 and vs[j - 1] > t:
+                    vs[j] = vs[j - 1]
+                    pts[2 * j], pts[2 * j + 1] = pts[2 * j - 2], pts[2 * j - 1]
+                    j -= 1
+                vs[j], pts[2 * j], pts[2 * j + 1] = t, tx, ty
+    a = _f(0)
+    for i in range(n - 2):
+        ax, ay = pts[0], pts[1]
+        bx, by = pts[2 * i + 2], pts[2 * i + 3]
+        cx_, cy_ = pts[2 * i + 4], pts[2 * i + 5]
+        tri = _f(_f(_f(_f(ax - cx_) * _f(by - cy_)) - _f(_f(ay - cy_) * _f(bx - cx_))) / _f(2))
+        a = _f(a + abs(tri))
+    return a
+
+
+def _inter_area(b1, b2):
+    c1, c2 = _corners(b1), _corners(b2)
+    pts = np.zeros(16 + 32, dtype=np.float32)
+    n = 0
+    for i in range(4):
+        if _inside(c1[2 * i], c1[2 * i + 1], c2):
+            pts[2 * n], pts[2 * n + 1] = c1[2 * i], c1[2 * i + 1]
+            n += 1
+        if _inside(c2[2 * i], c2[2 * i + 1], c1):
+            pts[2 * n], pts[2 * n + 1] = c2[2 * i], c2[2 * i + 1]
+            n += 1
+    for i in range(4):
+        for j in range(4):
+            h = _edge_hit(c1, c2, i, j)
+            if h is not None:
+                pts[2 * n], pts[2 * n + 1] = h
+                n += 1
+    return _poly_area_sorted(pts, n)
+
+
+def _iou_pair(q, b, criterion, is_3d):
+    """devRotateIoU2dEval / 3dEval (:248-293); first argument is the query box."""
+    a1, a2 = _f(q[2] * q[3]), _f(b[2] * b[3])
+    ai = _inter_area(q[:5], b[:5])
+    if not is_3d:
+        if criterion == -1:
+            return _f(ai / _f(_f(a1 + a2) - ai))
+        if criterion == 0:
+            return _f(ai / a1)
+        if criterion == 1:
+            return _f(ai / a2)
+        return ai
+    v1, v2 = _f(a1 * q[6]), _f(a2 * b[6])
+    if abs(_f(q[5] - b[5])) >= _f(_f(0.5) * _f(q[6] + b[6])):
+        h = _f(0)
+    else:
+        h = _f(min(_f(q[5] + _f(_f(0.5) * q[6])), _f(b[5] + _f(_f(0.5) * b[6])))
+               - max(_f(q[5] - _f(_f(0.5) * q[6])), _f(b[5] - _f(_f(0.5) * b[6]))))
+    vi = _f(ai * h)
+    if criterion == -1:
+        return _f(vi / _f(_f(v1 + v2) - vi))
+    if criterion == 0:
+        return _f(vi / v1)
+    if criterion == 1:
+        return _f(vi / v2)
+    return vi
+
+
+def rotate_iou(boxes, query_boxes, criterion=-1, is_3d=False):
+    """(N,5|7),(K,5|7) -> (N,K) float32; 3-D rows are permuted to
+    [x,y,l,w,rot,z,h] first (:383-384)."""
+    boxes = np.asarray(boxes).astype(np.float32)
+    query_boxes = np.asarray(query_boxes).astype(np.float32)
+    if is_3d:
+        perm = [0, 1, 3, 4, 6, 2, 5]
+        boxes, query_boxes = boxes[:, perm], query_boxes[:, perm]
+    N, K = boxes.shape[0], query_boxes.shape[0]
+    out = np.zeros((N, K), dtype=np.float32)
+    with np.errstate(all="ignore"):
+        for i in range(N):
+            for k in range(K):
+                out[i, k] = _iou_pair(query_boxes[k], boxes[i], criterion, is_3d)
+    return out

@@ -1,0 +1,191 @@
+"""CPU oracle (oracle/ref_numpy.py) == fixtures produced by the reference itself.
+
+Pins the oracle (section 3 of the task contract): the fixtures under tests/golden
+were written by tools/gen_golden.py, which imported /root/reference in the build
+container.  Integer / index / mask outputs must be bit-exact; float outputs equal
+to 1e-12 relative (same NumPy, same operation order -> normally bit-equal).
+"""
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+from planar_optical_flow_amd import synth
+
+PHI = R.laser_phi()
+
+
+def test_a1_phi(golden):
+    g = golden("phi")
+    assert np.array_equal(R.laser_phi(), g["phi_450"])
+    assert np.array_equal(R.laser_phi(np.radians(0.1), 3600), g["phi_3600"])
+    assert np.array_equal(R.laser_phi(np.radians(1.0), 225), g["phi_225"])
+
+
+@pytest.fixture(scope="module")
+def geo(golden):
+    g = golden("scan_geometry")
+    sb = synth.make_batch(seed=int(g["seed"]), B=int(g["B"]), T=2, mixed_classes=True)
+    return g, sb
+
+
+def test_a2_a3_a4_flow(geo):
+    g, sb = geo
+    for b in range(len(sb.scans)):
+        cur = sb.scans[b, -1]
+        xy = np.array(R.polar_to_xy(cur, PHI)).T
+        assert np.array_equal(xy, g["xy"][b])
+        d = R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b])
+        np.testing.assert_allclose(d, g["disp"][b], rtol=1e-12, atol=1e-15)
+        dc = R.flow_to_canonical(d, PHI)
+        np.testing.assert_allclose(dc, g["disp_canonical"][b], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(R.flow_to_global(dc, PHI), g["disp_back"][b], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(R.flow_target(cur, PHI, sb.odom0[b], sb.odom1[b]), g["flow_target"][b],
+                                   rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(R.flow_target(cur, PHI, sb.odom0[b], sb.odom1[b], True),
+                                   g["flow_target_canonical"][b], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(R.velocity_from_odometry(xy, sb.odom0[b], sb.odom1[b]), g["velocity"][b],
+                                   rtol=1e-12, atol=1e-15)
+        d32 = R.displacement_from_odometry(xy, sb.odom0[b].astype(np.float32), sb.odom1[b].astype(np.float32))
+        np.testing.assert_allclose(d32, g["disp_f32odom"][b], rtol=1e-12, atol=1e-15)
+
+
+def test_a3c(geo):
+    g, sb = geo
+    out = R.prepared_flow_target(sb.scans[0, -1], PHI, float(g["a3c_odom_t"]), g["a3c_odom"])
+    np.testing.assert_allclose(out, g["a3c_flow"], rtol=1e-12, atol=1e-15)
+
+
+def test_a5_roundtrip(geo):
+    g, sb = geo
+    r, p = R.canonical_to_det(sb.scans[0, -1], PHI, g["a5_dx"], g["a5_dy"])
+    assert np.array_equal(r, g["a5_det_r"]) and np.array_equal(p, g["a5_det_phi"])
+    x, y = R.det_to_canonical(sb.scans[0, -1], PHI, r, p)
+    assert np.array_equal(x, g["a5_back_x"]) and np.array_equal(y, g["a5_back_y"])
+
+
+def test_a6_a7_association_bit_exact(geo):
+    g, sb = geo
+    hits = 0
+    for b in range(len(sb.scans)):
+        cur = sb.scans[b, -1]
+        d = sb.dets[b]
+        cls, reg = R.regression_target(cur, PHI, d["wc"], d["wa"], d["wp"])
+        assert cls.dtype == np.int64 and reg.dtype == np.float32
+        assert np.array_equal(cls, g["target_cls"][b])
+        assert np.array_equal(reg, g["target_reg"][b])
+        cls, reg = R.regression_target(cur, PHI, d["wc"], d["wa"], d["wp"], pedestrian_only=True)
+        assert np.array_equal(cls, g["target_cls_ped"][b])
+        assert np.array_equal(reg, g["target_reg_ped"][b])
+        dets = list(d["wc"]) + list(d["wa"]) + list(d["wp"])
+        radii = [0.6] * len(d["wc"]) + [0.4] * len(d["wa"]) + [0.35] * len(d["wp"])
+        cd = R.closest_detection(cur, PHI, dets, radii)
+        assert np.array_equal(cd, g["closest"][b])
+        hits += int((cd > 0).sum())
+        xy = np.array(R.polar_to_xy(cur, PHI)).T
+        assert np.array_equal(R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]), g["dynamic_mask"][b])
+        assert np.array_equal(R.valid_point_mask(cur), g["valid_mask"][b])
+    assert hits > 0, "fixture must exercise at least one association"
+
+
+CUTOUT_CASES = {
+    "config_test": (0.5, 450, dict(fixed=False, centered=True, window_width=1.0, window_depth=0.5,
+                                   num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+    "dr_spaam": (0.5, 450, dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5,
+                                num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+    "defaults": (0.5, 450, dict(centered=False)),
+    "stride2": (0.5, 450, dict(stride=2, fixed=True, window_width=1.3, window_depth=0.7,
+                               num_cutout_pts=32, padding_val=29.99, area_mode=True)),
+    "dense3600": (0.1, 3600, dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5,
+                                  num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+    "near": (0.5, 450, dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5,
+                            num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+}
+
+
+@pytest.mark.parametrize("name", list(CUTOUT_CASES))
+def test_a8_cutout(golden, name):
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES[name]
+    phi = R.laser_phi(np.radians(inc), n)
+    scans, want = g[name + "_scans"], g[name + "_out"]
+    for b in range(len(scans)):
+        got = R.cutout(scans[b], phi, **kw)
+        assert got.dtype == np.float32 and got.shape == want[b].shape
+        assert np.array_equal(got, want[b])
+
+
+def test_a8_atan_modes_are_close(golden):
+    """The correctly rounded arctangent (what the HIP kernel uses) changes the
+    reference's result only where np.arctan(float32) is itself off by an ulp."""
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES["dr_spaam"]
+    phi = R.laser_phi(np.radians(inc), n)
+    a = R.cutout(g["dr_spaam_scans"][0], phi, **kw)
+    b = R.cutout(g["dr_spaam_scans"][0], phi, atan_mode="cr", **kw)
+    frac = np.mean(np.abs(a - b) > 1e-4)
+    assert frac < 2e-3
+
+
+def test_a11_nms(golden):
+    g = golden("nms")
+    for k in range(3):
+        xy, cls, inst = R.nms_predicted_center(g[f"scan{k}"], PHI, g[f"cls{k}"], g[f"reg{k}"], 0.5)
+        assert np.array_equal(inst, g[f"inst{k}"]) and inst.dtype == np.int32
+        assert np.array_equal(xy, g[f"xy{k}"])
+        assert np.array_equal(cls, g[f"keepcls{k}"])
+
+
+def test_a12_losses(golden):
+    g = golden("losses")
+    p, t, m = g["pred"], g["target"], g["mask"]
+    loss, err = R.epe_per_sample(p, t)
+    np.testing.assert_allclose(loss, g["proto_loss"], rtol=1e-5)
+    np.testing.assert_allclose(err, g["proto_err"], rtol=1e-5)
+    np.testing.assert_allclose(R.epe_masked(p, t, m), g["masked"], rtol=1e-5)
+    np.testing.assert_allclose(R.epe_masked(p, t), g["unmasked"], rtol=1e-5)
+    epe, aae = R.epe_aae_eval(p, t)
+    np.testing.assert_allclose(epe, g["epe"], rtol=1e-5)
+    np.testing.assert_allclose(aae, g["aae"], rtol=1e-4)
+
+
+def test_a9_band_correlation(golden):
+    g = golden("band_corr")
+    np.testing.assert_allclose(R.band_correlation(g["f1"], g["f2"]), g["out"], rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(R.band_correlation(g["f1s"], g["f2s"], 3, 3), g["outs"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name,alpha,w", [("spatial_attn", 0.5, 11), ("spatial_attn_w7", 0.3, 7)])
+def test_a10_spatial_attention(golden, name, alpha, w):
+    g = golden(name)
+    x, t = g["x"], g["tmpl"]
+    B, N = x.shape[:2]
+    out, band = R.spatial_attention(g["emb_x"], g["emb_t"], x.reshape(B, N, -1), t.reshape(B, N, -1), alpha, w)
+    np.testing.assert_allclose(band, g["band"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.reshape(x.shape), g["out"], rtol=1e-4, atol=1e-5)
+
+
+def test_a16_rotate_iou_known_answers():
+    """No runnable reference (numba.cuda): the reference's own __main__ pair
+    (src/utils/rotate_iou.py:407-412) plus analytic cases."""
+    b1 = np.array([[0, 0, 0.7, 1, 1, 1, 0]])
+    b2 = np.array([[0, 0, 0, 1, 1, 1, 0]])
+    np.testing.assert_allclose(R.rotate_iou(b1, b2, is_3d=True)[0, 0], 0.3 / 1.7, rtol=1e-6)
+    sq = np.array([[0, 0, 1, 1, 0.0]])
+    np.testing.assert_allclose(R.rotate_iou(sq, sq)[0, 0], 1.0, rtol=1e-6)
+    np.testing.assert_allclose(R.rotate_iou(sq, np.array([[3, 0, 1, 1, 0.0]]))[0, 0], 0.0, atol=1e-7)
+    np.testing.assert_allclose(R.rotate_iou(sq, np.array([[0.5, 0, 1, 1, 0.0]]))[0, 0], 1 / 3, rtol=1e-6)
+    oct_ = 2 * (np.sqrt(2) - 1)
+    np.testing.assert_allclose(R.rotate_iou(sq, np.array([[0, 0, 1, 1, np.pi / 4]]))[0, 0],
+                               oct_ / (2 - oct_), rtol=1e-5)
+
+
+def test_a13_fits_against_lapack():
+    rng = np.random.default_rng(3)
+    th = np.linspace(0.2, 2.0, 25)
+    seg = np.stack([1.5 + 0.4 * np.cos(th), -0.7 + 0.4 * np.sin(th)], axis=1) + rng.normal(0, 1e-3, (25, 2))
+    xc, yc, rc, _ = R.fit_circle(seg)
+    np.testing.assert_allclose([xc, yc, rc], [1.5, -0.7, 0.4], atol=5e-3)
+    from sklearn import linear_model
+    reg = linear_model.LinearRegression().fit(seg[:, 0].reshape(-1, 1), seg[:, 1].reshape(-1, 1))
+    k, b, _ = R.fit_line(seg)
+    np.testing.assert_allclose([k, b], [reg.coef_[0, 0], reg.intercept_[0]], rtol=1e-9)

@@ -1,0 +1,242 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE itself (build container only).
+
+The reference (/root/reference) is imported read-only with harness-side stubs for
+the non-arithmetic modules this image lacks (cv2, numba, tensorboardX, lzf,
+wandb) and the numpy aliases removed after 1.24 (np.int / np.float).  Nothing of
+the reference is copied: only seeded inputs and the outputs it produced are
+written, as compressed .npz data fixtures.
+
+    python tools/gen_golden.py            # rewrites tests/golden/
+
+The fixtures travel to the GPU box; the reference never does.
+"""
+import os
+import sys
+import types
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("POF_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def _install_stubs():
+    def stub(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    stub("cv2")
+    stub("tensorboardX", SummaryWriter=object)
+    stub("lzf")
+    stub("wandb")
+    stub("tensorboard")
+    stub("torch.utils.tensorboard", SummaryWriter=object)
+    nb, cu = stub("numba"), stub("numba.cuda")
+
+    def jit(*a, **k):
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+
+    nb.jit = cu.jit = jit
+    nb.cuda = cu
+    np.int = int
+    np.float = float
+    torch.Tensor.cuda = lambda s, *a, **k: s
+    sys.path.insert(0, REF)
+
+
+def main():
+    _install_stubs()
+    import src.utils.utils as u
+    from src.utils.dataset_dr_spaam import DROWDataset2
+    from src.depracted.model import prototype as proto
+    from src.depracted.model import dr_spaam as spaam
+    from src.utils import eval_utils
+
+    from planar_optical_flow_amd import synth
+
+    os.makedirs(OUT, exist_ok=True)
+    ds = DROWDataset2.__new__(DROWDataset2)  # only the two stateless mask helpers are used
+
+    # ---------------- A1: angle grids ---------------------------------------
+    np.savez_compressed(
+        os.path.join(OUT, "phi.npz"),
+        phi_450=u.get_laser_phi(),
+        phi_3600=u.get_laser_phi(np.radians(0.1), 3600),
+        phi_225=u.get_laser_phi(np.radians(1.0), 225),
+    )
+
+    # ---------------- A2-A7 on a seeded batch -------------------------------
+    B = 6
+    sb = synth.make_batch(seed=1, B=B, T=2, mixed_classes=True)
+    phi = u.get_laser_phi()
+    g = {"seed": 1, "B": B}
+    xy, disp, disp_c, ft, ft_c, vel, back = [], [], [], [], [], [], []
+    cls_all, reg_all, cls_ped, reg_ped, closest, dyn, valid = [], [], [], [], [], [], []
+    for b in range(B):
+        cur = sb.scans[b, -1]
+        o0, o1 = sb.odom0[b], sb.odom1[b]
+        p = np.array(u.rphi_to_xy(cur, phi)).T
+        xy.append(p)
+        d = u.get_displacement_from_odometry(p, o0, o1)
+        disp.append(d)
+        dc = u.global_to_canonical_flow(d, phi)
+        disp_c.append(dc)
+        back.append(u.canonical_to_global_flow(dc, phi))
+        ft.append(u.get_flow_target(cur, phi, o0, o1))
+        ft_c.append(u.get_flow_target(cur, phi, o0, o1, to_canonical=True))
+        vel.append(u.get_velocity_from_odometry(p, o0, o1))
+        de = sb.dets[b]
+        wc, wa, wp = [list(map(tuple, de[k])) for k in ("wc", "wa", "wp")]
+        c, r = u.get_regression_target(cur, phi, wc, wa, wp)
+        cls_all.append(c)
+        reg_all.append(r)
+        c, r = u.get_regression_target(cur, phi, wc, wa, wp, pedestrian_only=True)
+        cls_ped.append(c)
+        reg_ped.append(r)
+        dets = wc + wa + wp
+        radii = [0.6] * len(wc) + [0.4] * len(wa) + [0.35] * len(wp)
+        closest.append(np.asarray(u.closest_detection(cur, phi, dets, radii), dtype=np.int64))
+        dyn.append(ds._get_dynamic_mask(p, wc, wa, wp))
+        valid.append(ds._get_valid_point_mask(cur))
+    g.update(xy=np.array(xy), disp=np.array(disp), disp_canonical=np.array(disp_c),
+             disp_back=np.array(back), flow_target=np.array(ft), flow_target_canonical=np.array(ft_c),
+             velocity=np.array(vel), target_cls=np.array(cls_all), target_reg=np.array(reg_all),
+             target_cls_ped=np.array(cls_ped), target_reg_ped=np.array(reg_ped),
+             closest=np.array(closest), dynamic_mask=np.array(dyn), valid_mask=np.array(valid))
+    # odometry stored as float32 on disk in DROW (.odom2 'f4'): second variant
+    o0f, o1f = sb.odom0.astype(np.float32), sb.odom1.astype(np.float32)
+    g["disp_f32odom"] = np.array([u.get_displacement_from_odometry(np.array(xy[b]), o0f[b], o1f[b])
+                                  for b in range(B)])
+    # A5 round trip on random regression offsets
+    rng = np.random.default_rng(11)
+    dx, dy = rng.uniform(-0.5, 0.5, 450), rng.uniform(-0.5, 0.5, 450)
+    dr, dp = u.canonical_to_global(sb.scans[0, -1], phi, dx, dy)
+    cx, cy = u.global_to_canonical(sb.scans[0, -1], phi, dr, dp)
+    g.update(a5_dx=dx, a5_dy=dy, a5_det_r=dr, a5_det_phi=dp, a5_back_x=cx, a5_back_y=cy)
+    # A3c
+    odt = 0.08
+    od = np.array([0.03, -0.01, 0.02])
+    g.update(a3c_odom_t=odt, a3c_odom=od)
+    # bin/data_prepare.py is a script (runs on import): execute only its
+    # get_flow_target definition, taken from the parsed module
+    import ast
+    src_path = os.path.join(REF, "bin", "data_prepare.py")
+    tree = ast.parse(open(src_path).read(), src_path)
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_flow_target"]
+    ns = {"np": np, "rphi_to_xy": u.rphi_to_xy}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), src_path, "exec"), ns)
+    g["a3c_flow"] = ns["get_flow_target"](sb.scans[0, -1], phi, odt, od)
+    np.savez_compressed(os.path.join(OUT, "scan_geometry.npz"), **g)
+
+    # ---------------- A8: cutouts -------------------------------------------
+    cases = {
+        # config/config_test.yaml:19-26 (T=10 + cur)
+        "config_test": dict(T=11, N=450, inc=0.5, kw=dict(fixed=False, centered=True, window_width=1.0,
+                            window_depth=0.5, num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+        # config/dr_spaam.yaml:20-27 (T=5 + cur)
+        "dr_spaam": dict(T=6, N=450, inc=0.5, kw=dict(fixed=True, centered=True, window_width=1.0,
+                         window_depth=0.5, num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+        # function defaults (utils.py:259-270), no area mode, not centred
+        "defaults": dict(T=3, N=450, inc=0.5, kw=dict(centered=False)),
+        # stride 2, odd sizes, non-power-of-two depth
+        "stride2": dict(T=2, N=450, inc=0.5, kw=dict(stride=2, fixed=True, window_width=1.3,
+                        window_depth=0.7, num_cutout_pts=32, padding_val=29.99, area_mode=True)),
+        # BASELINE config 5 geometry: 3600 pts at 0.1 deg
+        "dense3600": dict(T=2, N=3600, inc=0.1, kw=dict(fixed=True, centered=True, window_width=1.0,
+                          window_depth=0.5, num_cutout_pts=56, padding_val=29.99, area_mode=True)),
+    }
+    gc = {}
+    for i, (name, c) in enumerate(cases.items()):
+        nb = 1 if name in ("config_test", "dense3600") else 2
+        sbc = synth.make_batch(seed=100 + i, B=nb, T=c["T"], N=c["N"], angle_inc=np.radians(c["inc"]))
+        ph = u.get_laser_phi(np.radians(c["inc"]), c["N"])
+        gc[name + "_scans"] = sbc.scans
+        gc[name + "_out"] = np.array([u.scans_to_cutout(sbc.scans[b], ph, **c["kw"]) for b in range(nb)])
+    # a near-field sample that drives s_area high (ranges down to the 1 cm clamp)
+    rng = np.random.default_rng(7)
+    near = rng.uniform(0.005, 0.6, (1, 3, 450)).astype(np.float32)
+    gc["near_scans"] = near
+    gc["near_out"] = np.array([u.scans_to_cutout(near[0], phi, **cases["dr_spaam"]["kw"])])
+    np.savez_compressed(os.path.join(OUT, "cutout.npz"), **gc)
+
+    # ---------------- A11: NMS ----------------------------------------------
+    rng = np.random.default_rng(21)
+    gn = {}
+    for k in range(3):
+        sbn = synth.make_batch(seed=200 + k, B=1, T=1)
+        scan = sbn.scans[0, 0]
+        pc = rng.permutation(450).astype(np.float64).reshape(450, 1) / 450.0 + rng.uniform(0, 1e-4)
+        pr = rng.normal(0, 0.3, (450, 2))
+        xy_, cl_, inst_ = u.nms_predicted_center(scan, phi, pc, pr, min_dist=0.5)
+        gn.update({f"scan{k}": scan, f"cls{k}": pc, f"reg{k}": pr, f"xy{k}": xy_, f"keepcls{k}": cl_,
+                   f"inst{k}": inst_})
+    np.savez_compressed(os.path.join(OUT, "nms.npz"), **gn)
+
+    # ---------------- A12: losses -------------------------------------------
+    rng = np.random.default_rng(31)
+    pred = rng.normal(0, 0.1, (5, 450, 2)).astype(np.float32)
+    tgt = rng.normal(0, 0.1, (5, 450, 2)).astype(np.float32)
+    msk = (rng.random((5, 450)) < 0.8).astype(np.float32)
+    tp, tt, tm = map(torch.from_numpy, (pred, tgt, msk))
+    l_proto, err_b = proto.flow_loss(tp, tt)
+    l_mask = spaam.flow_loss(tp, tt, tm)
+    l_nomask = spaam.flow_loss(tp, tt)
+    epe_b, aae_b = eval_utils.loss_fn_eval(tp, tt)
+    np.savez_compressed(os.path.join(OUT, "losses.npz"), pred=pred, target=tgt, mask=msk,
+                        proto_loss=l_proto.numpy(), proto_err=err_b.numpy(), masked=l_mask.numpy(),
+                        unmasked=l_nomask.numpy(), epe=epe_b.numpy(), aae=aae_b.numpy())
+
+    # ---------------- A9: banded patch correlation --------------------------
+    torch.manual_seed(41)
+    f1, f2 = torch.randn(2, 256, 57), torch.randn(2, 256, 57)
+    fused = proto.Prototype._fusion(None, f1, f2)
+    f1s, f2s = torch.randn(3, 16, 23), torch.randn(3, 16, 23)
+    fused_s = proto.Prototype._fusion(None, f1s, f2s, kernel_size=3, max_displacement=3)
+    np.savez_compressed(os.path.join(OUT, "band_corr.npz"), f1=f1.numpy(), f2=f2.numpy(), out=fused.numpy(),
+                        f1s=f1s.numpy(), f2s=f2s.numpy(), outs=fused_s.numpy())
+
+    # ---------------- A10: spatial attention --------------------------------
+    torch.manual_seed(51)
+    n_cut, n_ch, n_pts = 40, 32, 14
+    att = spaam._SpatialAttention(n_pts=n_pts, n_channel=n_ch, alpha=0.5, window_size=11)
+    att.eval()
+    with torch.no_grad():
+        att.conv[1].running_mean.normal_(0, 0.1)
+        att.conv[1].running_var.uniform_(0.5, 1.5)
+        x = torch.randn(2, n_cut, n_ch, n_pts)
+        t = torch.randn(2, n_cut, n_ch, n_pts)
+        out, band = att(x, t)
+        emb_x = att.conv(x.view(2 * n_cut, n_ch, n_pts)).view(2, n_cut, 128)
+        emb_t = att.conv(t.view(2 * n_cut, n_ch, n_pts)).view(2, n_cut, 128)
+    sd = {"sd_" + k.replace(".", "_"): v.numpy() for k, v in att.state_dict().items()}
+    np.savez_compressed(os.path.join(OUT, "spatial_attn.npz"), x=x.numpy(), tmpl=t.numpy(), out=out.numpy(),
+                        band=band.numpy(), emb_x=emb_x.numpy(), emb_t=emb_t.numpy(), **sd)
+    # a window of 7 with alpha 0.3 on odd sizes
+    torch.manual_seed(52)
+    att2 = spaam._SpatialAttention(n_pts=5, n_channel=8, alpha=0.3, window_size=7)
+    att2.eval()
+    with torch.no_grad():
+        x2, t2 = torch.randn(1, 19, 8, 5), torch.randn(1, 19, 8, 5)
+        out2, band2 = att2(x2, t2)
+        e2x = att2.conv(x2.view(19, 8, 5)).view(1, 19, 128)
+        e2t = att2.conv(t2.view(19, 8, 5)).view(1, 19, 128)
+    np.savez_compressed(os.path.join(OUT, "spatial_attn_w7.npz"), x=x2.numpy(), tmpl=t2.numpy(),
+                        out=out2.numpy(), band=band2.numpy(), emb_x=e2x.numpy(), emb_t=e2t.numpy())
+
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
+
+
+if __name__ == "__main__":
+    main()
