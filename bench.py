@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Throughput of the planar-flow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Headline workload = BASELINE.json configs[1]: batch 4096 synthetic 450-point
+scan pairs, flow-only (no detector head): one step = ONE launch of
+pof_scan_preprocess over one batch per rank (scan -> xy -> rigid-motion flow ->
+canonical frame, detection association, regression target, exclude mask).
+Inputs are resident in HBM before the timed region; a ring of distinct batches
+larger than the 256 MiB Infinity Cache is cycled so the stream really comes from
+HBM.  Batches shard over ranks with no data-path collective (weak scaling: every
+rank processes its own 4096 scans per step).
+
+One JSON line on stdout (rank 0).  Extra objects:
+  roofline      dominant kernel of the headline step (scan_preprocess_kernel)
+  cpu_baseline  the NumPy oracle (a port of the reference's per-sample path)
+                timed on this host's cores, rank 0, N=1 only, bounded sample
+  cutout        secondary measurement: the A8 cutout kernel at BASELINE config 3
+                shape with its own HBM roofline (not part of `value`)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+N_PTS = 450
+BATCH = 4096
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--ring", type=int, default=8, help="distinct resident batches cycled through")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_sample_worker(args):
+    """Reference execution shape: one __getitem__-style call per sample
+    (dataset_dr_spaam.py:384-409), NumPy oracle."""
+    os.environ["OMP_NUM_THREADS"] = "1"
+    from oracle import ref_numpy as R
+    scans, odom0, odom1, dets = args
+    phi = R.laser_phi()
+    out = []
+    for b in range(len(scans)):
+        cur = scans[b]
+        phi = R.laser_phi()
+        cls, reg = R.regression_target(cur, phi, [], [], dets[b])
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        flow = R.flow_to_canonical(R.displacement_from_odometry(xy, odom0[b], odom1[b]), phi)
+        mask = R.dynamic_mask(xy, [], [], dets[b]) * R.valid_point_mask(cur)
+        out.append((flow, cls, reg, mask))
+    # collate (dataset_dr_spaam.py:464-471)
+    return [np.array([o[k] for o in out]) for k in range(4)]
+
+
+def cpu_baseline(sb, budget_s=12.0):
+    import multiprocessing as mp
+    cores = min(os.cpu_count() or 1, 16)
+    n = 256 * cores
+    n = min(n, len(sb.scans))
+    chunks = np.array_split(np.arange(n), cores)
+    jobs = [(sb.scans[c, -1], sb.odom0[c], sb.odom1[c], [sb.dets[i]["wp"] for i in c]) for c in chunks]
+    with mp.get_context("fork").Pool(cores) as pool:
+        pool.map(cpu_sample_worker, jobs[:cores])  # warm-up
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            pool.map(cpu_sample_worker, jobs)
+            reps += 1
+            if time.perf_counter() - t0 > budget_s or reps >= 20:
+                break
+        dt = time.perf_counter() - t0
+    return {"value": n * reps / dt, "unit": "scans/s", "cores": cores, "kind": "port",
+            "sample": "%d x %d scans of the headline workload, per-sample NumPy oracle calls + collate in a "
+                      "%d-process pool (reference DataLoader shape)" % (reps, n, cores)}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    from planar_optical_flow_amd import synth
+    B, N = a.batch, N_PTS
+    sb = synth.make_batch(seed=2 + 1000 * rank, B=B, T=2, N=N)
+    # CPU baseline first: the worker pool is forked before this process touches the GPU
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(sb)
+
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from planar_optical_flow_amd import ops
+
+    offs, rphi, cls = sb.det_csr()
+    tab = ops.phi_table(device=dev)
+    ring = []
+    for r in range(a.ring):
+        sh = (r * 509) % B  # distinct memory and distinct content per ring slot
+        scans = torch.from_numpy(np.roll(sb.scans, sh, axis=0)).to(dev)
+        o0 = torch.from_numpy(np.roll(sb.odom0, sh, axis=0)).to(dev)
+        o1 = torch.from_numpy(np.roll(sb.odom1, sh, axis=0)).to(dev)
+        counts = np.roll(np.diff(offs), sh)
+        order = np.roll(np.arange(B), sh)
+        ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
+        det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
+        outs = {
+            "flow": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
+            "target_cls": torch.empty((B, N), dtype=torch.int64, device=dev),
+            "target_reg": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
+            "exclude_mask": torch.empty((B, N), dtype=torch.float32, device=dev),
+        }
+        ring.append((scans, o0, o1, det, outs))
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+
+    def step(i):
+        scans, o0, o1, det, outs = ring[i % a.ring]
+        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- optional hipGraph of one trip round the ring --------------------------
+    graph = None
+    if not a.no_graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for i in range(a.ring):
+                step(i)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            for i in range(a.ring):
+                step(i)
+
+    def run(k):
+        if graph is not None:
+            full, rem = divmod(k, a.ring)
+            for _ in range(full):
+                graph.replay()
+            for i in range(rem):
+                step(i)
+        else:
+            for i in range(k):
+                step(i)
+
+    run(a.warmup)
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(a.steps)
+    ev1.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- parity of what was just computed (outside the timed region) ------------
+    from oracle import ref_numpy as R
+    scans, o0, o1, det, outs = ring[0]
+    phi = R.laser_phi()
+    flow = outs["flow"][:64].cpu().numpy()
+    epe = 0.0
+    for b in range(64):
+        cur = sb.scans[b, -1]
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
+        epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
+
+    result = None
+    if rank == 0:
+        # algorithmic bytes per scan: 4N range row in; out 8N flow f32 +
+        # 8N target_cls int64 + 8N target_reg + 4N exclude mask  = 32N = 14 400 B
+        bytes_per_scan = 4 * N + (8 + 8 + 8 + 4) * N
+        launch_ms = dev_ms / a.steps
+        achieved = bytes_per_scan * B / (launch_ms * 1e-3) / 1e9
+        result = {
+            "metric": "scans/sec, flow-only preprocess of 450-pt synthetic scan pairs, batch 4096 per GPU "
+                      "(+ flow EPE vs reference oracle)",
+            "value": world * B * a.steps / dt,
+            "unit": "scans/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: batch %d x 450-pt scan pairs, flow-only "
+                                   "(A1-A7 fused: xy, displacement flow, canonical frame, association, "
+                                   "regression target, exclude mask), float32 outputs" % B,
+                       "global_batch": world * B, "ring_batches": a.ring,
+                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "parallelism": "batch-sharded x%d, no collective" % world},
+            "epe_vs_oracle_m": epe,
+            "roofline": {"bound": "hbm", "kernel": "scan_preprocess_kernel<float,2>",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms},
+        }
+        if not a.no_extra:
+            result["cutout"] = bench_cutout(ops, synth, tab, dev)
+            result["spatial_attention"] = bench_attention(ops, dev)
+        if cpu is not None:
+            result["cpu_baseline"] = cpu
+            result["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _time_kernel(torch, fn, iters, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def bench_cutout(ops, synth, tab, dev):
+    """A8 at BASELINE config 3 shape: T=5, 450 pts, P=56, dr_spaam.yaml window."""
+    import torch
+    B, T, N, P = 2048, 5, N_PTS, 56
+    sb = synth.make_batch(seed=3, B=B, T=T, N=N)
+    scans = torch.from_numpy(sb.scans).to(dev)
+    out = torch.empty((B, N, T, P), dtype=torch.float32, device=dev)
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=P,
+              padding_val=29.99, area_mode=True)
+    ms = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out, **kw), 10)
+    per_sample = T * N * 4 + N * T * P * 4  # 513 000 B
+    ach = per_sample * B / (ms * 1e-3) / 1e9
+    return {"workload": "cutout T=5 N=450 P=56 area_mode, batch %d" % B, "ms_per_call": ms,
+            "samples_per_s": B / (ms * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "cutout_area_kernel + cutout_kernel", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+def bench_attention(ops, dev):
+    """A10 at DR-SPAAM shape: N=450, F=256*14, E=128, w=11."""
+    import torch
+    B, N, E, F = 64, N_PTS, 128, 3584
+    g = torch.Generator(device=dev).manual_seed(10)
+    ex = torch.randn((B, N, E), device=dev, generator=g) * 0.3
+    et = torch.randn((B, N, E), device=dev, generator=g) * 0.3
+    x = torch.randn((B, N, F), device=dev, generator=g)
+    t = torch.randn((B, N, F), device=dev, generator=g)
+    out = torch.empty_like(x)
+    ms = _time_kernel(torch, lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), 10)
+    per = 3 * N * F * 4 + 2 * N * E * 4 + 2 * N * 11 * 4
+    ach = per * B / (ms * 1e-3) / 1e9
+    return {"workload": "spatial attention N=450 F=3584 E=128 w=11, batch %d" % B, "ms_per_call": ms,
+            "roofline": {"bound": "hbm", "kernel": "attn_band_kernel + attn_merge_kernel<11>", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+if __name__ == "__main__":
+    main()

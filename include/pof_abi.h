@@ -1,0 +1,187 @@
+/*
+ * pof_abi.h -- C ABI of libpof_hip.so, the MI355X (gfx950) implementation of the
+ * per-point planar-flow hot path of huzjkevin/planar_optical_flow.
+ *
+ * Conventions
+ *   - every entry point returns int: POF_OK (0) or a negative POF_E_* code;
+ *   - all array arguments are DEVICE pointers owned by the caller; the library
+ *     never allocates or frees user-visible memory and keeps no global state
+ *     (re-entrant, thread-safe); scratch space is passed in explicitly;
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream);
+ *   - shapes are C-contiguous unless a stride argument says otherwise.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative
+ * to the reference checkout).
+ */
+#ifndef POF_ABI_H
+#define POF_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define POF_ABI_VERSION 1
+
+enum {
+    POF_OK = 0,
+    POF_E_BADARG = -1, /* null pointer / illegal enum / negative size          */
+    POF_E_SHAPE = -2,  /* sizes inconsistent with each other or with a limit   */
+    POF_E_LAUNCH = -3, /* the HIP runtime reported an error on launch          */
+    POF_E_WORKSPACE = -4 /* caller workspace too small                         */
+};
+
+typedef void *pof_stream_t; /* hipStream_t */
+
+int pof_abi_version(void);
+const char *pof_error_string(int code);
+
+/* ------------------------------------------------------------------------
+ * A1  get_laser_phi(angle_inc, num_pts)            src/utils/utils.py:25-29
+ * Fills tab[0..N) = phi, tab[N..3N) = (cos phi_i, sin phi_i) interleaved, all
+ * float64.  phi is bit-identical to numpy.linspace(-fov/2, fov/2, N).
+ * ---------------------------------------------------------------------- */
+int pof_laser_phi(double angle_inc, int num_pts, double *tab /* [3*N] */, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A2-A7 fused per-sample preprocessing of the CURRENT scan of each window:
+ *   rphi_to_xy                          src/utils/utils.py:47-48
+ *   get_displacement_from_odometry      src/utils/utils.py:639-662  (kind 0)
+ *   get_flow_target                     src/utils/utils.py:204-229  (kind 1)
+ *   get_velocity_from_odometry          src/utils/utils.py:609-636  (kind 2)
+ *   global_to_canonical_flow            src/utils/utils.py:62-75    (canonical != 0)
+ *   closest_detection / get_regression_target   src/utils/utils.py:147-185, 232-256
+ *   _get_dynamic_mask / _get_valid_point_mask   src/utils/dataset_dr_spaam.py:511-529
+ * i.e. the arithmetic of DROWDataset2.__getitem__ (dataset_dr_spaam.py:384-409)
+ * for a whole batch in one launch; the collate (dataset_dr_spaam.py:464-471) is
+ * implicit because outputs are written in batched layout.
+ *
+ * ranges        current-scan rows, float32; row b starts at ranges + b*sample_stride
+ * tab           output of pof_laser_phi for this N
+ * odom0/odom1   [B][3] float64 (x, y, phi); may be NULL when flow and xy are NULL
+ * out_f64       0: xy/flow are float32, 1: float64
+ * xy, flow      [B][N][2], either may be NULL
+ * det_offsets   [B+1] int32 CSR offsets into det_rphi/det_cls, or NULL to skip
+ *               association and the dynamic mask
+ * det_rphi      [D][2] float64 (r, phi); det_cls [D] uint8 in {0,1,2} = wc, wa, wp
+ * assoc_radius  [3] radius per class for closest_detection (reference 0.6,0.4,0.35)
+ * labels        [3] class label per class (reference 1,2,3; pedestrian_only: x,x,1)
+ * dyn_radius    [3] radius per class for the dynamic mask (reference 2.5,2.0,2.0)
+ * closest       [B][N] int64, 1-based detection index within the sample, 0 = none
+ * target_cls    [B][N] int64;  target_reg [B][N][2] float32
+ * dyn_mask, valid_mask, exclude_mask   [B][N] float32 in {0,1}
+ * Any output pointer may be NULL.
+ * ---------------------------------------------------------------------- */
+int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,
+                        const double *tab, const double *odom0, const double *odom1,
+                        int flow_kind, int canonical, int out_f64, void *xy, void *flow,
+                        const int32_t *det_offsets, const double *det_rphi, const uint8_t *det_cls,
+                        const double *assoc_radius, const int32_t *labels, const double *dyn_radius,
+                        int64_t *closest, int64_t *target_cls, float *target_reg,
+                        float *dyn_mask, float *valid_mask, float *exclude_mask,
+                        pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A4 stand-alone frame rotation of a flow field
+ *   global_to_canonical_flow / canonical_to_global_flow(_torch)
+ *                                             src/utils/utils.py:62-105
+ * flow_in/out [B][N][2], float32 (is_f64=0) or float64; may alias.
+ * ---------------------------------------------------------------------- */
+int pof_rotate_flow(const void *flow_in, void *flow_out, const double *tab, int B, int N,
+                    int to_canonical, int is_f64, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A5 global_to_canonical / canonical_to_global   src/utils/utils.py:55-59,109-126
+ * Batched over [B][N]; det_* and d* are per point.  float64.
+ * ---------------------------------------------------------------------- */
+int pof_det_to_canonical(const float *ranges, const double *tab, const double *det_r,
+                         const double *det_phi, double *dx, double *dy, int B, int N,
+                         pof_stream_t stream);
+int pof_canonical_to_det(const float *ranges, const double *tab, const double *dx, const double *dy,
+                         double *det_r, double *det_phi, int B, int N, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A8 scans_to_cutout                            src/utils/utils.py:259-334
+ * scans [B][T][N] float32 -> out [B][N/stride][T][P] float32.
+ * workspace: int32[B] (per-sample area factor), caller provided.
+ * half-angle arctangent: correctly rounded float32.
+ * dbg_lo (optional, may be NULL): [B][P][T][N/stride] int32 copy of
+ * inds_ct_low for the bit-exact index tests.
+ * ---------------------------------------------------------------------- */
+int pof_cutout(const float *scans, int B, int T, int N, const double *tab, int stride, int centered,
+               int fixed, double window_width, double window_depth, int num_cutout_pts,
+               double padding_val, int area_mode, float *out, int32_t *workspace,
+               int32_t *dbg_lo, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A11 nms_predicted_center                      src/utils/utils.py:535-571
+ * One scan per batch entry.  pred_cls [B][N] float64 scores, pred_reg [B][N][2].
+ * Outputs: det_xy [B][N][2] float64 and det_cls [B][N] float64 compacted to the
+ * first num_det[b] rows, instance_mask [B][N] int32.  Scores must be distinct
+ * (the reference's argsort is unstable on ties).
+ * workspace: at least pof_nms_workspace_bytes(B, N) bytes.
+ * ---------------------------------------------------------------------- */
+size_t pof_nms_workspace_bytes(int B, int N);
+int pof_nms_predicted_center(const float *ranges, const double *tab, const double *pred_cls,
+                             const double *pred_reg, double min_dist, int B, int N, double *det_xy,
+                             double *det_cls, int32_t *num_det, int32_t *instance_mask,
+                             void *workspace, size_t workspace_bytes, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A12 flow_loss / loss_fn_eval
+ *   src/depracted/model/prototype.py:27-32, src/depracted/model/dr_spaam.py:22-27,
+ *   src/utils/eval_utils.py:129-134
+ * pred/target [B][N][2] float32, mask [B][N] float32 or NULL.
+ * epe_sum[b] = sum_i |pred-target| (masked), cnt[b] = number of points counted,
+ * aae_sum[b] = sum_i |atan2(p0,p1) - atan2(t0,t1)| (radians); all float64 [B].
+ * ---------------------------------------------------------------------- */
+int pof_flow_errors(const float *pred, const float *target, const float *mask, int B, int N,
+                    double *epe_sum, double *aae_sum, double *cnt, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A9 Prototype._fusion               src/depracted/model/prototype.py:118-156
+ * feat1/feat2 [B][C][n] float32 -> out [B][2*max_disp+1][n] float32.
+ * ---------------------------------------------------------------------- */
+int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C, int n,
+                         int kernel_size, int max_disp, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A10 _SpatialAttention.forward (everything after the embedding conv)
+ *                                   src/depracted/model/dr_spaam.py:163-217
+ * emb_x/emb_t [B][N][E] float32; x/tmpl [B][N][F] float32 (F = channels*pts).
+ * band [B][N][w] pre-softmax similarities (clamped duplicates kept),
+ * prob [B][N][w] softmax weights with duplicates zeroed (scratch, also useful
+ * for the backward pass), out [B][N][F] = alpha*x + (1-alpha)*sum_k prob*tmpl.
+ * ---------------------------------------------------------------------- */
+int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x, const float *tmpl,
+                          int B, int N, int E, int F, int window, double alpha, float *band,
+                          float *prob, float *out, pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A13 jump-distance segmentation + per-segment least squares
+ *   src/depracted/model/adaboost_person_det.py:71-90 (cuts), :102-210 (features)
+ * ranges [B][N] float32.  seg_id [B][N] int32 (segment index of every point),
+ * num_seg [B] int32, feat [B][max_seg][16] float64 (columns: see DESIGN.md).
+ * ---------------------------------------------------------------------- */
+int pof_segment_features(const float *ranges, const double *tab, int B, int N, double jump_dist,
+                         int max_seg, int32_t *seg_id, int32_t *num_seg, double *feat,
+                         pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A16 rotate_iou_gpu_eval                     src/utils/rotate_iou.py:297-404
+ * boxes [N][5|7], query [K][5|7] float32 (already permuted to the kernel's
+ * x,y,l,w,rot,z,h order for 3-D) -> iou [N][K] float32.
+ * Batched form: boxes [G][N][s], query [G][K][s], iou [G][N][K], with optional
+ * per-group valid counts n_valid[G], k_valid[G] (NULL = all).
+ * ---------------------------------------------------------------------- */
+int pof_rotate_iou(const float *boxes, const float *query, float *iou, int G, int N, int K,
+                   const int32_t *n_valid, const int32_t *k_valid, int criterion, int is_3d,
+                   pof_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POF_ABI_H */

@@ -1,0 +1,92 @@
+"""ctypes binding of libpof_hip.so (include/pof_abi.h).
+
+There is no CPU fallback: if the shared library is missing or a call returns a
+non-zero code this module raises.  The library is located in-tree
+(planar_optical_flow_amd/lib/libpof_hip.so, produced by
+``python -m planar_optical_flow_amd.build`` / ``__graft_entry__.build()``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpof_hip.so")
+
+POF_OK, POF_E_BADARG, POF_E_SHAPE, POF_E_LAUNCH, POF_E_WORKSPACE = 0, -1, -2, -3, -4
+
+_p = C.c_void_p
+_i = C.c_int
+_d = C.c_double
+_ll = C.c_longlong
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pof_abi.h one to one
+SIGNATURES = {
+    "pof_abi_version": (_i, []),
+    "pof_error_string": (C.c_char_p, [_i]),
+    "pof_laser_phi": (_i, [_d, _i, _p, _p]),
+    "pof_scan_preprocess": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _p, _p, _p,
+                                 _p, _p, _p, _p, _p, _p, _p]),
+    "pof_rotate_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
+    "pof_det_to_canonical": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "pof_canonical_to_det": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
+    "pof_cutout": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _d, _d, _i, _d, _i, _p, _p, _p, _p]),
+    "pof_nms_workspace_bytes": (_sz, [_i, _i]),
+    "pof_nms_predicted_center": (_i, [_p, _p, _p, _p, _d, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "pof_flow_errors": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p]),
+    "pof_band_correlation": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pof_spatial_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
+    "pof_segment_features": (_i, [_p, _p, _i, _i, _d, _i, _p, _p, _p, _p]),
+    "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),
+}
+
+
+class PofError(RuntimeError):
+    def __init__(self, fn, code, msg):
+        super().__init__("%s failed with code %d: %s" % (fn, code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load(path=None):
+    """Load the library and declare every prototype.  Raises if it is absent:
+    the product path has no fallback."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError(
+            "libpof_hip.so not found at %s -- build it with "
+            "`python -m planar_optical_flow_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:
+        raise ImportError("libpof_hip.so lacks exports declared in include/pof_abi.h: %s" % missing)
+    if lib.pof_abi_version() != 1:
+        raise ImportError("libpof_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; non-zero -> exception.
+    POF_E_BADARG maps to AssertionError like the reference's input guards."""
+    lib = load()
+    code = getattr(lib, name)(*args)
+    if code != POF_OK:
+        msg = lib.pof_error_string(code).decode()
+        if code == POF_E_BADARG:
+            raise AssertionError("%s: %s" % (name, msg))
+        raise PofError(name, code, msg)
+    return code

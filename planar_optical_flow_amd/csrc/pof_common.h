@@ -1,0 +1,58 @@
+// Shared device/host helpers for libpof_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pof_abi.h"
+
+#define POF_WAVE 64
+
+#define POF_CHECK_LAUNCH()                                   \
+    do {                                                     \
+        if (hipGetLastError() != hipSuccess) return POF_E_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t pof_stream(pof_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// The translation units are built with -ffp-contract=off: a*b+c is two
+// roundings unless fma() is written out.  That is what makes the float64 index
+// math of the cutout and the association distances bit-identical to NumPy.
+
+// Correctly rounded x / c for a divisor known per launch; `rc` = RN(1/c).
+// q0 = RN(x*rc) is within 1 ulp of x/c; the exact FMA residual and one FMA
+// correction give RN(x/c) (Markstein).  Checked against '/' on 1.2e9 random
+// operands for the divisors this library uses (tools/divconst_check.c).
+__device__ __forceinline__ double pof_div_const(double x, double c, double rc)
+{
+    double q = x * rc;
+    double r = fma(-q, c, x);
+    return fma(r, rc, q);
+}
+
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_sum_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

@@ -1,0 +1,383 @@
+"""Batched device API: torch tensors in HBM -> libpof_hip.so (C ABI) -> torch tensors.
+
+torch is used only as the owner of device memory and streams.  Every function
+validates shapes/dtypes on the host before a kernel sees them and launches on
+torch's current HIP stream.  No CPU fallback exists: a missing library or a CPU
+tensor raises.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_TAB_CACHE = {}
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _dev(t, dtype, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise TypeError("%s must be a tensor on the HIP device (no CPU path)" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise ValueError("%s must be contiguous" % name)
+    return t
+
+
+def phi_table(angle_inc=np.radians(0.5), num_pts=450, device="cuda"):
+    """A1: device table [3N] float64 = phi | (cos, sin) interleaved.  Cached."""
+    device = torch.device(device)
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    key = (float(angle_inc), int(num_pts), device.index)
+    tab = _TAB_CACHE.get(key)
+    if tab is None:
+        tab = torch.empty(3 * num_pts, dtype=torch.float64, device=device)
+        with torch.cuda.device(device):
+            _lib.call("pof_laser_phi", float(angle_inc), int(num_pts), _ptr(tab), _stream())
+        _TAB_CACHE[key] = tab
+    return tab
+
+
+def laser_phi(angle_inc=np.radians(0.5), num_pts=450, device="cuda"):
+    return phi_table(angle_inc, num_pts, device)[:num_pts]
+
+
+class DetCSR:
+    """Ragged per-sample detections on the device: offsets [B+1] int32,
+    rphi [D,2] float64, cls [D] uint8 (0 wc, 1 wa, 2 wp)."""
+
+    def __init__(self, offsets, rphi, cls):
+        self.offsets = _dev(offsets, torch.int32, "det offsets")
+        self.rphi = _dev(rphi, torch.float64, "det rphi")
+        self.cls = _dev(cls, torch.uint8, "det cls")
+        if self.rphi.dim() != 2 or self.rphi.shape[1] != 2 or self.cls.shape[0] != self.rphi.shape[0]:
+            raise ValueError("det_rphi must be [D,2] and det_cls [D]")
+
+    @staticmethod
+    def from_numpy(offsets, rphi, cls, device="cuda"):
+        offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        if offsets[0] != 0 or np.any(np.diff(offsets) < 0) or offsets[-1] != len(rphi):
+            raise ValueError("CSR offsets must start at 0, be non-decreasing and end at D")
+        # keep at least one element so data_ptr() is valid for D == 0
+        r = np.ascontiguousarray(rphi, dtype=np.float64).reshape(-1, 2)
+        c = np.ascontiguousarray(cls, dtype=np.uint8)
+        if len(r) == 0:
+            r, c = np.zeros((1, 2)), np.zeros(1, dtype=np.uint8)
+            d = DetCSR(torch.from_numpy(offsets).to(device), torch.from_numpy(r).to(device),
+                       torch.from_numpy(c).to(device))
+            return d
+        return DetCSR(torch.from_numpy(offsets).to(device), torch.from_numpy(r).to(device),
+                      torch.from_numpy(c).to(device))
+
+
+FLOW_DISPLACEMENT, FLOW_TARGET, FLOW_VELOCITY = 0, 1, 2
+
+
+def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLOW_DISPLACEMENT,
+                    canonical=True, out_dtype=torch.float32, want=("flow",),
+                    assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3), dyn_radius=(2.5, 2.0, 2.0),
+                    out=None):
+    """A2-A7 fused, one launch.
+
+    scans: [B,T,N] (the last row of each window is the current scan) or [B,N].
+    want: subset of {"xy","flow","closest","target_cls","target_reg","dyn_mask",
+          "valid_mask","exclude_mask"}.  `out` may hold preallocated tensors.
+    Returns a dict of device tensors.
+    """
+    scans = _dev(scans, torch.float32, "scans")
+    if scans.dim() == 3:
+        B, T, N = scans.shape
+        stride, off = T * N, (T - 1) * N
+    elif scans.dim() == 2:
+        B, N = scans.shape
+        stride, off = N, 0
+    else:
+        raise ValueError("scans must be [B,T,N] or [B,N]")
+    tab = _dev(tab, torch.float64, "tab")
+    if tab.numel() != 3 * N:
+        raise ValueError("angle table is for %d points, scans have %d" % (tab.numel() // 3, N))
+    want = set(want)
+    known = {"xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "valid_mask", "exclude_mask"}
+    if not want <= known:
+        raise ValueError("unknown outputs: %s" % sorted(want - known))
+    need_det = bool(want & {"closest", "target_cls", "target_reg", "dyn_mask", "exclude_mask"})
+    if need_det and dets is None:
+        raise ValueError("association / dynamic-mask outputs need detections")
+    if "flow" in want:
+        odom0 = _dev(odom0, torch.float64, "odom0")
+        odom1 = _dev(odom1, torch.float64, "odom1")
+        if tuple(odom0.shape) != (B, 3) or tuple(odom1.shape) != (B, 3):
+            raise ValueError("odometry must be [B,3]")
+    if dets is not None and dets.offsets.numel() != B + 1:
+        raise ValueError("detection offsets must have B+1 entries")
+    if out_dtype not in (torch.float32, torch.float64):
+        raise TypeError("out_dtype must be float32 or float64")
+    dev = scans.device
+    out = {} if out is None else out
+
+    def buf(name, shape, dtype):
+        if name not in want:
+            return None
+        t = out.get(name)
+        if t is None:
+            t = torch.empty(shape, dtype=dtype, device=dev)
+            out[name] = t
+        else:
+            _dev(t, dtype, name)
+            if tuple(t.shape) != tuple(shape):
+                raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), tuple(shape)))
+        return t
+
+    xy = buf("xy", (B, N, 2), out_dtype)
+    flow = buf("flow", (B, N, 2), out_dtype)
+    closest = buf("closest", (B, N), torch.int64)
+    tcls = buf("target_cls", (B, N), torch.int64)
+    treg = buf("target_reg", (B, N, 2), torch.float32)
+    dyn = buf("dyn_mask", (B, N), torch.float32)
+    val = buf("valid_mask", (B, N), torch.float32)
+    exc = buf("exclude_mask", (B, N), torch.float32)
+    ar = (C.c_double * 3)(*assoc_radius)
+    lb = (C.c_int32 * 3)(*labels)
+    dr = (C.c_double * 3)(*dyn_radius)
+    base = scans.data_ptr() + 4 * off
+    with torch.cuda.device(dev):
+        # grid.y carries the sample index: chunk very large batches
+        step = 65535
+        for s in range(0, max(B, 1), step):
+            n = min(step, B - s)
+            if n <= 0:
+                break
+
+            def sl(t, per):
+                return None if t is None else C.c_void_p(t.data_ptr() + s * per * t.element_size())
+
+            _lib.call(
+                "pof_scan_preprocess", C.c_void_p(base + 4 * s * stride), stride, n, N, _ptr(tab),
+                sl(odom0, 3) if "flow" in want else None, sl(odom1, 3) if "flow" in want else None,
+                int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
+                sl(xy, 2 * N), sl(flow, 2 * N),
+                sl(dets.offsets, 1) if need_det else None,
+                _ptr(dets.rphi) if need_det else None, _ptr(dets.cls) if need_det else None,
+                ar, lb, dr, sl(closest, N), sl(tcls, N), sl(treg, 2 * N), sl(dyn, N), sl(val, N),
+                sl(exc, N), _stream())
+    return out
+
+
+def rotate_flow(flow, tab, to_canonical=True, out=None):
+    """A4 on a [B,N,2] (or [N,2]) float32/float64 device tensor."""
+    if flow.dtype not in (torch.float32, torch.float64):
+        raise TypeError("flow must be float32 or float64")
+    flow = _dev(flow, flow.dtype, "flow")
+    N = flow.shape[-2]
+    B = flow.numel() // (2 * N)
+    if flow.shape[-1] != 2 or tab.numel() != 3 * N:
+        raise ValueError("flow must be [...,N,2] matching the angle table")
+    out = torch.empty_like(flow) if out is None else out
+    with torch.cuda.device(flow.device):
+        _lib.call("pof_rotate_flow", _ptr(flow), _ptr(out), _ptr(tab), B, N, int(bool(to_canonical)),
+                  int(flow.dtype == torch.float64), _stream())
+    return out
+
+
+def det_to_canonical(ranges, tab, det_r, det_phi):
+    """A5 forward, batched per point: ranges [B,N] float32, det_* [B,N] float64."""
+    ranges = _dev(ranges, torch.float32, "ranges")
+    B, N = ranges.shape
+    det_r = _dev(det_r, torch.float64, "det_r")
+    det_phi = _dev(det_phi, torch.float64, "det_phi")
+    dx, dy = torch.empty_like(det_r), torch.empty_like(det_r)
+    with torch.cuda.device(ranges.device):
+        _lib.call("pof_det_to_canonical", _ptr(ranges), _ptr(tab), _ptr(det_r), _ptr(det_phi), _ptr(dx),
+                  _ptr(dy), B, N, _stream())
+    return dx, dy
+
+
+def canonical_to_det(ranges, tab, dx, dy):
+    """A5 inverse."""
+    ranges = _dev(ranges, torch.float32, "ranges")
+    B, N = ranges.shape
+    dx = _dev(dx, torch.float64, "dx")
+    dy = _dev(dy, torch.float64, "dy")
+    r, p = torch.empty_like(dx), torch.empty_like(dx)
+    with torch.cuda.device(ranges.device):
+        _lib.call("pof_canonical_to_det", _ptr(ranges), _ptr(tab), _ptr(dx), _ptr(dy), _ptr(r), _ptr(p),
+                  B, N, _stream())
+    return r, p
+
+
+def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, window_depth=1.0,
+           num_cutout_pts=48, padding_val=29.99, area_mode=False, out=None, return_debug=False):
+    """A8 for a batch: scans [B,T,N] float32 -> [B, ceil(N/stride), T, P] float32."""
+    scans = _dev(scans, torch.float32, "scans")
+    if scans.dim() != 3:
+        raise ValueError("scans must be [B,T,N]")
+    B, T, N = scans.shape
+    if tab.numel() != 3 * N:
+        raise ValueError("angle table does not match N")
+    Ns = (N + stride - 1) // stride
+    P = int(num_cutout_pts)
+    if out is None:
+        out = torch.empty((B, Ns, T, P), dtype=torch.float32, device=scans.device)
+    else:
+        _dev(out, torch.float32, "out")
+        if tuple(out.shape) != (B, Ns, T, P):
+            raise ValueError("out has the wrong shape")
+    dbg = torch.empty((B, P, T, Ns), dtype=torch.int32, device=scans.device) if return_debug else None
+    with torch.cuda.device(scans.device):
+        step = 65535
+        for s in range(0, B, step):
+            n = min(step, B - s)
+            ws = torch.empty(max(n, 1), dtype=torch.int32, device=scans.device)
+            _lib.call("pof_cutout", _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
+                      int(bool(fixed)), float(window_width), float(window_depth), P, float(padding_val),
+                      int(bool(area_mode)), _ptr(out[s:s + n]), _ptr(ws),
+                      _ptr(dbg[s:s + n]) if dbg is not None else None, _stream())
+            if return_debug:
+                dbg_area = ws
+    if return_debug:
+        return out, {"lo": dbg, "s_area": dbg_area}
+    return out
+
+
+def nms_predicted_center(ranges, tab, pred_cls, pred_reg, min_dist=0.5):
+    """A11 batched: ranges [B,N] f32, pred_cls [B,N] f64, pred_reg [B,N,2] f64 ->
+    (det_xy [B,N,2], det_cls [B,N], num_det [B] int32, instance_mask [B,N] int32)."""
+    ranges = _dev(ranges, torch.float32, "ranges")
+    B, N = ranges.shape
+    pred_cls = _dev(pred_cls, torch.float64, "pred_cls")
+    pred_reg = _dev(pred_reg, torch.float64, "pred_reg")
+    if tuple(pred_cls.shape) != (B, N) or tuple(pred_reg.shape) != (B, N, 2):
+        raise AssertionError("pred_cls must be [B,N] and pred_reg [B,N,2]")
+    dev = ranges.device
+    det_xy = torch.zeros((B, N, 2), dtype=torch.float64, device=dev)
+    det_cls = torch.zeros((B, N), dtype=torch.float64, device=dev)
+    num = torch.zeros(B, dtype=torch.int32, device=dev)
+    inst = torch.zeros((B, N), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pof_nms_predicted_center", _ptr(ranges), _ptr(tab), _ptr(pred_cls), _ptr(pred_reg),
+                  float(min_dist), B, N, _ptr(det_xy), _ptr(det_cls), _ptr(num), _ptr(inst), None, 0,
+                  _stream())
+    return det_xy, det_cls, num, inst
+
+
+def flow_errors(pred, target, mask=None):
+    """A12 reductions: returns (epe_sum [B], aae_sum [B] radians, count [B]) float64."""
+    pred = _dev(pred, torch.float32, "pred")
+    target = _dev(target, torch.float32, "target")
+    if pred.shape != target.shape or pred.dim() != 3 or pred.shape[-1] != 2:
+        raise ValueError("pred/target must be [B,N,2]")
+    B, N = pred.shape[:2]
+    if mask is not None:
+        mask = _dev(mask, torch.float32, "mask")
+        if tuple(mask.shape) != (B, N):
+            raise ValueError("mask must be [B,N]")
+    dev = pred.device
+    e = torch.empty(B, dtype=torch.float64, device=dev)
+    a = torch.empty(B, dtype=torch.float64, device=dev)
+    c = torch.empty(B, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pof_flow_errors", _ptr(pred), _ptr(target), _ptr(mask), B, N, _ptr(e), _ptr(a), _ptr(c),
+                  _stream())
+    return e, a, c
+
+
+def band_correlation(feat1, feat2, kernel_size=3, max_displacement=5, out=None):
+    """A9: [B,C,n] x2 float32 -> [B, 2*max_displacement+1, n] float32."""
+    feat1 = _dev(feat1, torch.float32, "feat1")
+    feat2 = _dev(feat2, torch.float32, "feat2")
+    if feat1.shape != feat2.shape or feat1.dim() != 3:
+        raise ValueError("features must be two [B,C,n] tensors of equal shape")
+    B, Cc, n = feat1.shape
+    D = 2 * max_displacement + 1
+    if out is None:
+        out = torch.empty((B, D, n), dtype=torch.float32, device=feat1.device)
+    with torch.cuda.device(feat1.device):
+        step = 65535
+        for s in range(0, B, step):
+            m = min(step, B - s)
+            _lib.call("pof_band_correlation", _ptr(feat1[s:s + m]), _ptr(feat2[s:s + m]), _ptr(out[s:s + m]),
+                      m, Cc, n, int(kernel_size), int(max_displacement), _stream())
+    return out
+
+
+def spatial_attention(emb_x, emb_t, x, tmpl, alpha=0.5, window_size=11, out=None):
+    """A10 after the embedding: emb_* [B,N,E], x/tmpl [B,N,...] float32 ->
+    (out like x, band [B,N,w], prob [B,N,w])."""
+    emb_x = _dev(emb_x, torch.float32, "emb_x")
+    emb_t = _dev(emb_t, torch.float32, "emb_t")
+    x = _dev(x, torch.float32, "x")
+    tmpl = _dev(tmpl, torch.float32, "tmpl")
+    if emb_x.shape != emb_t.shape or emb_x.dim() != 3 or x.shape != tmpl.shape:
+        raise ValueError("shape mismatch")
+    B, N, E = emb_x.shape
+    if x.shape[0] != B or x.shape[1] != N:
+        raise ValueError("x must be [B,N,...]")
+    F = x.numel() // (B * N)
+    W = 2 * int(window_size / 2) + 1
+    dev = x.device
+    band = torch.empty((B, N, W), dtype=torch.float32, device=dev)
+    prob = torch.empty((B, N, W), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        step = 65535
+        for s in range(0, B, step):
+            m = min(step, B - s)
+            _lib.call("pof_spatial_attention", _ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]), _ptr(x[s:s + m]),
+                      _ptr(tmpl[s:s + m]), m, N, E, F, int(window_size), float(alpha), _ptr(band[s:s + m]),
+                      _ptr(prob[s:s + m]), _ptr(out[s:s + m]), _stream())
+    return out, band, prob
+
+
+def segment_features(ranges, tab, jump_dist=0.5, max_seg=None):
+    """A13: ranges [B,N] float32 -> (seg_id [B,N] int32, num_seg [B] int32, feat [B,max_seg,16] f64)."""
+    ranges = _dev(ranges, torch.float32, "ranges")
+    B, N = ranges.shape
+    max_seg = N if max_seg is None else int(max_seg)
+    dev = ranges.device
+    seg_id = torch.empty((B, N), dtype=torch.int32, device=dev)
+    num = torch.empty(B, dtype=torch.int32, device=dev)
+    feat = torch.full((B, max_seg, 16), float("nan"), dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pof_segment_features", _ptr(ranges), _ptr(tab), B, N, float(jump_dist), max_seg,
+                  _ptr(seg_id), _ptr(num), _ptr(feat), _stream())
+    return seg_id, num, feat
+
+
+_PERM_3D = [0, 1, 3, 4, 6, 2, 5]
+
+
+def rotate_iou(boxes, query_boxes, criterion=-1, is_3d=False, n_valid=None, k_valid=None):
+    """A16: boxes [N,s] / [G,N,s], query [K,s] / [G,K,s] float32 device tensors in the
+    REFERENCE column order (3-D: x,y,z,l,w,h,rot) -> iou [N,K] / [G,N,K] float32."""
+    if boxes.dim() == 2:
+        return rotate_iou(boxes[None], query_boxes[None], criterion, is_3d)[0]
+    s = 7 if is_3d else 5
+    if boxes.shape[-1] != s or query_boxes.shape[-1] != s or boxes.shape[0] != query_boxes.shape[0]:
+        raise ValueError("boxes must be [G,N,%d] and query [G,K,%d]" % (s, s))
+    b = boxes.to(torch.float32)
+    q = query_boxes.to(torch.float32)
+    if is_3d:
+        b, q = b[..., _PERM_3D], q[..., _PERM_3D]
+    b = _dev(b.contiguous(), torch.float32, "boxes")
+    q = _dev(q.contiguous(), torch.float32, "query_boxes")
+    G, N, K = b.shape[0], b.shape[1], q.shape[1]
+    out = torch.zeros((G, N, K), dtype=torch.float32, device=b.device)
+    if n_valid is not None:
+        n_valid = _dev(n_valid, torch.int32, "n_valid")
+    if k_valid is not None:
+        k_valid = _dev(k_valid, torch.int32, "k_valid")
+    with torch.cuda.device(b.device):
+        _lib.call("pof_rotate_iou", _ptr(b), _ptr(q), _ptr(out), G, N, K, _ptr(n_valid), _ptr(k_valid),
+                  int(criterion), int(bool(is_3d)), _stream())
+    return out

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a
+GPU and exports every symbol include/pof_abi.h declares; host-side argument
+validation rejects bad input before anything is launched."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from planar_optical_flow_amd import build, _lib
+    build.build(verbose=False)
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(REPO, "include", "pof_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pof_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 15
+    raw = ctypes.CDLL(os.path.join(REPO, "planar_optical_flow_amd", "lib", "libpof_hip.so"))
+    for n in names:
+        assert hasattr(raw, n), "libpof_hip.so does not export %s" % n
+
+
+def test_binding_matches_header(lib):
+    from planar_optical_flow_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared_symbols()
+    assert lib.pof_abi_version() == 1
+    assert lib.pof_error_string(-2).decode().startswith("inconsistent")
+
+
+def test_bad_arguments_are_rejected_without_launch(lib):
+    """NULL pointers / bad sizes return POF_E_BADARG before any HIP call."""
+    from planar_optical_flow_amd import _lib
+    with pytest.raises(AssertionError):
+        _lib.call("pof_laser_phi", 0.01, 450, None, None)
+    with pytest.raises(AssertionError):
+        _lib.call("pof_cutout", None, 1, 1, 450, None, 1, 1, 1, 1.0, 1.0, 56, 29.99, 0, None, None, None, None)
+    with pytest.raises(AssertionError):
+        _lib.call("pof_rotate_iou", None, None, None, 1, 1, 1, None, None, -1, 0, None)
+
+
+def test_no_cpu_fallback():
+    """The product path refuses CPU tensors instead of silently computing on the host."""
+    from planar_optical_flow_amd import ops
+    with pytest.raises(TypeError):
+        ops.scan_preprocess(torch.zeros(2, 450), torch.zeros(1350, dtype=torch.float64), want=("xy",))
+    with pytest.raises(TypeError):
+        ops.cutout(torch.zeros(1, 2, 450), torch.zeros(1350, dtype=torch.float64))
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    from planar_optical_flow_amd import _lib
+    with pytest.raises(ImportError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_synth_is_deterministic():
+    from planar_optical_flow_amd import synth
+    a = synth.make_batch(5, 4, T=3)
+    b = synth.make_batch(5, 4, T=3)
+    assert np.array_equal(a.scans, b.scans) and np.array_equal(a.odom1, b.odom1)
+    o, r, c = a.det_csr()
+    assert o[0] == 0 and o[-1] == len(r) == len(c)

@@ -1,0 +1,418 @@
+"""HIP path (through the C ABI) vs the CPU oracle and the reference's golden vectors.
+
+Run on the GPU box:  python -m pytest tests -m gpu -x -q
+Tolerances are stated per test.  Integer / index / mask outputs are bit-exact.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as R
+from planar_optical_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from planar_optical_flow_amd import ops as _ops
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return _ops
+
+
+def T(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(DEV)
+
+
+def csr(ops, sb, pedestrian_only=False):
+    o, r, c = sb.det_csr(pedestrian_only)
+    return ops.DetCSR.from_numpy(o, r, c, DEV)
+
+
+# ---------------------------------------------------------------- A1
+def test_phi_table(ops, golden):
+    g = golden("phi")
+    for key, inc, n in (("phi_450", 0.5, 450), ("phi_3600", 0.1, 3600), ("phi_225", 1.0, 225)):
+        tab = ops.phi_table(np.radians(inc), n, DEV).cpu().numpy()
+        assert np.array_equal(tab[:n], g[key]), "phi must be bit-identical to numpy.linspace"
+        cs = tab[n:].reshape(n, 2)
+        # device cos/sin vs libm: at most 1 ulp of float64
+        assert np.max(np.abs(cs[:, 0] - np.cos(g[key]))) <= 2.3e-16
+        assert np.max(np.abs(cs[:, 1] - np.sin(g[key]))) <= 2.3e-16
+
+
+# ---------------------------------------------------------------- A2-A7 vs golden
+@pytest.fixture(scope="module")
+def geo(golden):
+    g = golden("scan_geometry")
+    sb = synth.make_batch(seed=int(g["seed"]), B=int(g["B"]), T=2, mixed_classes=True)
+    return g, sb
+
+
+def test_preprocess_golden_f64(ops, geo):
+    g, sb = geo
+    tab = ops.phi_table()
+    out = ops.scan_preprocess(
+        T(sb.scans), tab, T(sb.odom0), T(sb.odom1), csr(ops, sb), flow_kind=ops.FLOW_DISPLACEMENT,
+        canonical=True, out_dtype=torch.float64,
+        want=("xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "valid_mask", "exclude_mask"))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out["xy"].cpu().numpy(), g["xy"], rtol=0, atol=1e-14)
+    # flow vectors: float64 path, tolerance 1e-12 m (reference is float64 with float32 rotation)
+    np.testing.assert_allclose(out["flow"].cpu().numpy(), g["disp_canonical"], rtol=0, atol=1e-12)
+    assert np.array_equal(out["closest"].cpu().numpy(), g["closest"])
+    assert np.array_equal(out["target_cls"].cpu().numpy(), g["target_cls"])
+    np.testing.assert_allclose(out["target_reg"].cpu().numpy(), g["target_reg"], rtol=0, atol=1e-6)
+    assert np.array_equal(out["dyn_mask"].cpu().numpy().astype(np.float64), g["dynamic_mask"])
+    assert np.array_equal(out["valid_mask"].cpu().numpy(), g["valid_mask"])
+    assert np.array_equal(out["exclude_mask"].cpu().numpy().astype(np.float64),
+                          g["dynamic_mask"] * g["valid_mask"])
+    assert (g["closest"] > 0).sum() > 0
+
+
+def test_preprocess_golden_f32_epe(ops, geo):
+    """float32 output: EPE vs the reference <= 1e-4 m (north_star), measured ~1e-6."""
+    g, sb = geo
+    tab = ops.phi_table()
+    out = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), want=("flow",))
+    f = out["flow"].cpu().numpy().astype(np.float64)
+    epe = np.linalg.norm(f - g["disp_canonical"], axis=-1).mean()
+    assert epe < 1e-5
+    out = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), canonical=False, want=("flow",))
+    np.testing.assert_allclose(out["flow"].cpu().numpy(), g["disp"], rtol=0, atol=5e-6)
+
+
+def test_flow_kinds_golden(ops, geo):
+    g, sb = geo
+    tab = ops.phi_table()
+    kw = dict(out_dtype=torch.float64, want=("flow",))
+    o = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), flow_kind=ops.FLOW_TARGET,
+                            canonical=False, **kw)
+    np.testing.assert_allclose(o["flow"].cpu().numpy(), g["flow_target"], rtol=0, atol=1e-12)
+    o = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), flow_kind=ops.FLOW_TARGET,
+                            canonical=True, **kw)
+    np.testing.assert_allclose(o["flow"].cpu().numpy(), g["flow_target_canonical"], rtol=0, atol=1e-12)
+    o = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), flow_kind=ops.FLOW_VELOCITY,
+                            canonical=False, **kw)
+    np.testing.assert_allclose(o["flow"].cpu().numpy(), g["velocity"], rtol=0, atol=1e-12)
+
+
+def test_pedestrian_only_golden(ops, geo):
+    g, sb = geo
+    tab = ops.phi_table()
+    out = ops.scan_preprocess(T(sb.scans), tab, dets=csr(ops, sb, pedestrian_only=True),
+                              labels=(1, 1, 1), want=("target_cls", "target_reg"))
+    assert np.array_equal(out["target_cls"].cpu().numpy(), g["target_cls_ped"])
+    np.testing.assert_allclose(out["target_reg"].cpu().numpy(), g["target_reg_ped"], rtol=0, atol=1e-6)
+
+
+def test_rotate_flow_roundtrip_golden(ops, geo):
+    g, sb = geo
+    tab = ops.phi_table()
+    d = T(g["disp"])
+    c = ops.rotate_flow(d, tab, True)
+    np.testing.assert_allclose(c.cpu().numpy(), g["disp_canonical"], rtol=0, atol=1e-14)
+    back = ops.rotate_flow(c, tab, False)
+    np.testing.assert_allclose(back.cpu().numpy(), g["disp_back"], rtol=0, atol=1e-14)
+    c32 = ops.rotate_flow(d.float(), tab, True)
+    np.testing.assert_allclose(c32.cpu().numpy(), g["disp_canonical"], rtol=0, atol=1e-6)
+
+
+def test_a5_golden(ops, geo):
+    g, sb = geo
+    tab = ops.phi_table()
+    rng_ = T(sb.scans[0:1, -1])
+    r, p = ops.canonical_to_det(rng_, tab, T(g["a5_dx"][None]), T(g["a5_dy"][None]))
+    np.testing.assert_allclose(r.cpu().numpy()[0], g["a5_det_r"], rtol=1e-14)
+    np.testing.assert_allclose(p.cpu().numpy()[0], g["a5_det_phi"], rtol=0, atol=1e-14)
+    x, y = ops.det_to_canonical(rng_, tab, r, p)
+    np.testing.assert_allclose(x.cpu().numpy()[0], g["a5_back_x"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(y.cpu().numpy()[0], g["a5_back_y"], rtol=0, atol=1e-13)
+
+
+# ---------------------------------------------------------------- A2-A7 at BASELINE size vs oracle
+def test_preprocess_b4096_vs_oracle(ops):
+    """BASELINE config 2 shape (B=4096, 450 pts).  Oracle on a strided subset,
+    size-independent properties on everything."""
+    B = 4096
+    sb = synth.make_batch(seed=2, B=B, T=2)
+    tab = ops.phi_table()
+    scans = T(sb.scans)
+    det = csr(ops, sb)
+    out = ops.scan_preprocess(scans, tab, T(sb.odom0), T(sb.odom1), det, out_dtype=torch.float64,
+                              want=("xy", "flow", "closest", "target_cls", "target_reg", "exclude_mask"))
+    phi = R.laser_phi()
+    flow = out["flow"].cpu().numpy()
+    cls = out["target_cls"].cpu().numpy()
+    reg = out["target_reg"].cpu().numpy()
+    exc = out["exclude_mask"].cpu().numpy()
+    for b in range(0, B, 37):
+        cur = sb.scans[b, -1]
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        want = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
+        np.testing.assert_allclose(flow[b], want, rtol=0, atol=1e-12)
+        d = sb.dets[b]
+        c, r = R.regression_target(cur, phi, d["wc"], d["wa"], d["wp"])
+        assert np.array_equal(cls[b], c)
+        np.testing.assert_allclose(reg[b], r, rtol=0, atol=1e-6)
+        m = R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]) * R.valid_point_mask(cur)
+        assert np.array_equal(exc[b].astype(np.float64), m)
+    # properties over the full batch
+    glob = ops.rotate_flow(out["flow"], tab, False)
+    again = ops.rotate_flow(glob, tab, True)
+    assert torch.max(torch.abs(again - out["flow"])).item() < 1e-14       # rotation round trip
+    xy_t = out["xy"]
+    r_back = torch.sqrt(xy_t[..., 0] ** 2 + xy_t[..., 1] ** 2)
+    assert torch.max(torch.abs(r_back - scans[:, -1].double())).item() < 1e-13   # |xy| = r
+    lab = out["target_cls"]
+    assert set(torch.unique(lab).tolist()) <= {0, 3}
+    assert torch.all((out["closest"] > 0) == (lab > 0))
+    # zero motion -> zero flow
+    z = ops.scan_preprocess(scans, tab, T(sb.odom0), T(sb.odom0), want=("flow",))
+    assert torch.count_nonzero(z["flow"]).item() == 0
+
+
+def test_preprocess_edge_cases(ops):
+    tab = ops.phi_table()
+    # no detections anywhere
+    sb = synth.make_batch(seed=9, B=3, T=1, max_legs=0)
+    out = ops.scan_preprocess(T(sb.scans), tab, dets=csr(ops, sb), want=("target_cls", "closest", "dyn_mask"))
+    assert torch.count_nonzero(out["target_cls"]).item() == 0
+    assert torch.all(out["dyn_mask"] == 1)
+    # empty batch
+    e = ops.scan_preprocess(torch.empty((0, 2, 450), dtype=torch.float32, device=DEV), tab,
+                            torch.empty((0, 3), dtype=torch.float64, device=DEV),
+                            torch.empty((0, 3), dtype=torch.float64, device=DEV), want=("flow",))
+    assert e["flow"].shape == (0, 450, 2)
+    # odd N (scalar path) and many detections (> one LDS tile of 64)
+    n = 451
+    tab_o = ops.phi_table(np.radians(0.5), n)
+    phi = R.laser_phi(np.radians(0.5), n)
+    rng = np.random.default_rng(5)
+    scans = rng.uniform(0.5, 25, (2, n)).astype(np.float32)
+    dets = np.stack([rng.uniform(1, 10, 150), rng.uniform(phi[0], phi[-1], 150)], axis=1)
+    offs = np.array([0, 150, 150], dtype=np.int32)
+    d = ops.DetCSR.from_numpy(offs, dets, np.full(150, 2, np.uint8), DEV)
+    out = ops.scan_preprocess(T(scans), tab_o, dets=d, want=("closest", "target_cls", "target_reg", "dyn_mask"))
+    want = R.closest_detection(scans[0], phi, list(map(tuple, dets)), [0.35] * 150)
+    assert np.array_equal(out["closest"].cpu().numpy()[0], want)
+    assert torch.count_nonzero(out["closest"][1]).item() == 0
+    xy = np.array(R.polar_to_xy(scans[0], phi)).T
+    assert np.array_equal(out["dyn_mask"].cpu().numpy()[0].astype(np.float64),
+                          R.dynamic_mask(xy, [], [], dets))
+    # wrong shapes are rejected on the host before any launch
+    with pytest.raises(ValueError):
+        ops.scan_preprocess(T(scans), tab, want=("xy",))
+    with pytest.raises(TypeError):
+        ops.scan_preprocess(torch.zeros(2, 450), tab, want=("xy",))
+
+
+# ---------------------------------------------------------------- A8
+from cases import CUTOUT_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(CUTOUT_CASES))
+def test_cutout_bit_exact_vs_oracle(ops, golden, name):
+    """Same definition of the half-angle (correctly rounded float32 atan):
+    indices and values must be bit-identical."""
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES[name]
+    phi = R.laser_phi(np.radians(inc), n)
+    tab = ops.phi_table(np.radians(inc), n)
+    scans = g[name + "_scans"]
+    got, dbg = ops.cutout(T(scans), tab, return_debug=True, **kw)
+    got = got.cpu().numpy()
+    lo = dbg["lo"].cpu().numpy()
+    for b in range(len(scans)):
+        want, wd = R.cutout(scans[b], phi, atan_mode="cr", return_debug=True, **kw)
+        assert np.array_equal(lo[b], wd["lo"]), "inds_ct_low must be bit-exact"
+        if kw.get("area_mode"):
+            assert int(dbg["s_area"][b].item()) == wd["s_area"]
+        assert np.array_equal(got[b], want)
+
+
+@pytest.mark.parametrize("name", list(CUTOUT_CASES))
+def test_cutout_vs_reference_golden(ops, golden, name):
+    """Against the reference's own output (np.arctan on float32, last bit CPU
+    dependent): identical except where that last bit moves an index across an
+    integer; stated tolerance: <= 0.2 % of elements differ by more than 1e-4."""
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES[name]
+    tab = ops.phi_table(np.radians(inc), n)
+    got = ops.cutout(T(g[name + "_scans"]), tab, **kw).cpu().numpy()
+    want = g[name + "_out"]
+    assert got.shape == want.shape
+    frac = np.mean(np.abs(got - want) > 1e-4)
+    assert frac < 2e-3, frac
+
+
+def test_cutout_batch_properties(ops):
+    """BASELINE config 3 shape at reduced batch + properties at B=512."""
+    kw = CUTOUT_CASES["dr_spaam"][2]
+    sb = synth.make_batch(seed=3, B=512, T=5)
+    tab = ops.phi_table()
+    scans = T(sb.scans)
+    out = ops.cutout(scans, tab, **kw)
+    assert out.shape == (512, 450, 5, 56)
+    assert torch.all(out.abs() <= 1.0 + 1e-6)          # clipped to +-depth and normalised
+    phi = R.laser_phi()
+    for b in (0, 255, 511):
+        assert np.array_equal(out[b].cpu().numpy(), R.cutout(sb.scans[b], phi, atan_mode="cr", **kw))
+    # per-sample independence: a sample's cutout does not depend on its batch neighbours
+    solo = ops.cutout(scans[100:101].contiguous(), tab, **kw)
+    assert torch.equal(solo[0], out[100])
+    # fixed=True: each time row only depends on its own scan row
+    one = ops.cutout(scans[7:8, 2:3].contiguous(), tab, **kw)
+    assert torch.equal(one[0, :, 0], out[7, :, 2])
+
+
+# ---------------------------------------------------------------- A11
+def test_nms_golden(ops, golden):
+    g = golden("nms")
+    tab = ops.phi_table()
+    scans = np.stack([g[f"scan{k}"] for k in range(3)])
+    cls = np.stack([g[f"cls{k}"][:, 0] for k in range(3)])
+    reg = np.stack([g[f"reg{k}"] for k in range(3)])
+    xy, dc, num, inst = ops.nms_predicted_center(T(scans), tab, T(cls), T(reg), 0.5)
+    for k in range(3):
+        m = int(num[k].item())
+        assert m == len(g[f"xy{k}"])
+        assert np.array_equal(inst[k].cpu().numpy(), g[f"inst{k}"])
+        np.testing.assert_allclose(xy[k, :m].cpu().numpy(), g[f"xy{k}"], rtol=0, atol=1e-12)
+        assert np.array_equal(dc[k, :m].cpu().numpy(), g[f"keepcls{k}"][:, 0])
+
+
+# ---------------------------------------------------------------- A12
+def test_flow_errors_golden(ops, golden):
+    g = golden("losses")
+    p, t, m = T(g["pred"]), T(g["target"]), T(g["mask"])
+    e, a, c = ops.flow_errors(p, t)
+    n = g["pred"].shape[1]
+    np.testing.assert_allclose((e / n).cpu().numpy(), g["epe"], rtol=1e-5)
+    np.testing.assert_allclose((a / n * 180 / np.pi).cpu().numpy(), g["aae"], rtol=1e-4)
+    np.testing.assert_allclose((e / n).mean().item(), g["proto_loss"], rtol=1e-5)
+    np.testing.assert_allclose((e.sum() / c.sum()).item(), g["unmasked"], rtol=1e-5)
+    e, a, c = ops.flow_errors(p, t, m)
+    np.testing.assert_allclose((e.sum() / c.sum()).item(), g["masked"], rtol=1e-5)
+    assert c.sum().item() == g["mask"].sum()
+
+
+# ---------------------------------------------------------------- A9
+def test_band_correlation_golden(ops, golden):
+    g = golden("band_corr")
+    out = ops.band_correlation(T(g["f1"]), T(g["f2"]), 3, 5).cpu().numpy()
+    # float32 accumulation over 768 products of N(0,1) values: 1e-3 absolute
+    np.testing.assert_allclose(out, g["out"], rtol=1e-4, atol=1e-3)
+    out = ops.band_correlation(T(g["f1s"]), T(g["f2s"]), 3, 3).cpu().numpy()
+    np.testing.assert_allclose(out, g["outs"], rtol=1e-4, atol=1e-4)
+
+
+def test_band_correlation_wide(ops):
+    """BASELINE config 5 geometry (n = 450) against the oracle: several tiles."""
+    rng = np.random.default_rng(8)
+    f1 = rng.normal(0, 1, (2, 64, 450)).astype(np.float32)
+    f2 = rng.normal(0, 1, (2, 64, 450)).astype(np.float32)
+    out = ops.band_correlation(T(f1), T(f2), 3, 5).cpu().numpy()
+    np.testing.assert_allclose(out, R.band_correlation(f1.astype(np.float64), f2.astype(np.float64)),
+                               rtol=1e-4, atol=1e-3)
+
+
+# ---------------------------------------------------------------- A10
+@pytest.mark.parametrize("name,alpha,w", [("spatial_attn", 0.5, 11), ("spatial_attn_w7", 0.3, 7)])
+def test_spatial_attention_golden(ops, golden, name, alpha, w):
+    g = golden(name)
+    out, band, prob = ops.spatial_attention(T(g["emb_x"]), T(g["emb_t"]), T(g["x"]), T(g["tmpl"]), alpha, w)
+    np.testing.assert_allclose(band.cpu().numpy(), g["band"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(prob.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
+def test_spatial_attention_full_width(ops):
+    """DR-SPAAM shape per sample (N=450, F=256*14) against the oracle."""
+    rng = np.random.default_rng(12)
+    B, N, E, F = 2, 450, 128, 3584
+    ex = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    et = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    x = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    t = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    out, band, _ = ops.spatial_attention(T(ex), T(et), T(x), T(t), 0.5, 11)
+    wo, wb = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
+                                 t.astype(np.float64), 0.5, 11)
+    np.testing.assert_allclose(band.cpu().numpy(), wb, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(out.cpu().numpy(), wo, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------- A13
+def test_segment_features_vs_oracle(ops):
+    sb = synth.make_batch(seed=13, B=4, T=1, dropout=0.0)
+    tab = ops.phi_table()
+    phi = R.laser_phi()
+    scans = sb.scans[:, 0]
+    sid, num, feat = ops.segment_features(T(scans), tab, 0.5)
+    for b in range(4):
+        cuts, want = R.segment_features(scans[b], phi, 0.5)
+        S = len(cuts) + 1
+        assert int(num[b].item()) == S
+        ids = np.zeros(450, dtype=np.int32)
+        ids[cuts] = 1
+        assert np.array_equal(sid[b].cpu().numpy(), np.cumsum(ids))        # cut indices bit-exact
+        got = feat[b, :S].cpu().numpy()
+        n = want[:, 0]
+        assert np.array_equal(got[:, 0], n)
+        simple = [1, 2, 3, 4, 8, 9]
+        np.testing.assert_allclose(got[:, simple], want[:, simple], rtol=1e-9, atol=1e-12, equal_nan=True)
+        # fits: compare on well conditioned segments (>= 8 points, not collinear)
+        good = (n >= 8) & (want[:, 7] < 50)
+        assert good.sum() > 0
+        np.testing.assert_allclose(got[good][:, [12, 13]], want[good][:, [12, 13]], rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(got[good][:, [7, 14, 15, 6]], want[good][:, [7, 14, 15, 6]], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(got[good][:, [5, 10, 11]], want[good][:, [5, 10, 11]], rtol=1e-6, atol=1e-8)
+
+
+# ---------------------------------------------------------------- A16
+def test_rotate_iou_known_answers(ops):
+    b1 = torch.tensor([[0, 0, 0.7, 1, 1, 1, 0]], device=DEV)
+    b2 = torch.tensor([[0, 0, 0, 1, 1, 1, 0.0]], device=DEV)
+    np.testing.assert_allclose(ops.rotate_iou(b1, b2, is_3d=True)[0, 0].item(), 0.3 / 1.7, rtol=1e-6)
+    sq = torch.tensor([[0, 0, 1, 1, 0.0]], device=DEV)
+    q = torch.tensor([[0, 0, 1, 1, 0.0], [3, 0, 1, 1, 0], [0.5, 0, 1, 1, 0], [0, 0, 1, 1, np.pi / 4]], device=DEV)
+    got = ops.rotate_iou(sq, q).cpu().numpy()[0]
+    oct_ = 2 * (np.sqrt(2) - 1)
+    np.testing.assert_allclose(got, [1.0, 0.0, 1 / 3, oct_ / (2 - oct_)], rtol=1e-5, atol=1e-7)
+
+
+def test_rotate_iou_vs_oracle(ops):
+    rng = np.random.default_rng(16)
+
+    def boxes(n, s):
+        b = np.zeros((n, s), dtype=np.float32)
+        b[:, :2] = rng.uniform(-1, 1, (n, 2))
+        if s == 5:
+            b[:, 2:4] = rng.uniform(0.3, 1.5, (n, 2))
+            b[:, 4] = rng.uniform(-np.pi, np.pi, n)
+        else:
+            b[:, 2] = rng.uniform(-0.3, 0.3, n)
+            b[:, 3:6] = rng.uniform(0.3, 1.5, (n, 3))
+            b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+        return b
+
+    for s, is3d in ((5, False), (7, True)):
+        bx, qx = boxes(70, s), boxes(33, s)
+        got = ops.rotate_iou(T(bx), T(qx), is_3d=is3d).cpu().numpy()
+        want = R.rotate_iou(bx, qx, is_3d=is3d)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-5)       # reference tolerance (float32)
+        assert (want > 0.05).sum() > 50
+    # batched with ragged valid counts
+    bx = np.stack([boxes(1, 5) for _ in range(6)])
+    qx = np.stack([boxes(9, 5) for _ in range(6)])
+    kv = np.array([9, 3, 0, 5, 9, 1], dtype=np.int32)
+    got = ops.rotate_iou(T(bx), T(qx), k_valid=T(kv)).cpu().numpy()
+    for gidx in range(6):
+        want = R.rotate_iou(bx[gidx], qx[gidx][:kv[gidx]])
+        np.testing.assert_allclose(got[gidx][:, :kv[gidx]], want, rtol=0, atol=1e-5)
+        assert np.all(got[gidx][:, kv[gidx]:] == 0)
