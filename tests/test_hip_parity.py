@@ -172,9 +172,9 @@ def test_preprocess_b4096_vs_oracle(ops):
     lab = out["target_cls"]
     assert set(torch.unique(lab).tolist()) <= {0, 3}
     assert torch.all((out["closest"] > 0) == (lab > 0))
-    # zero motion -> zero flow
+    # zero motion -> flow is zero up to the float32 rounding of R0^T R0 (as in the reference)
     z = ops.scan_preprocess(scans, tab, T(sb.odom0), T(sb.odom0), want=("flow",))
-    assert torch.count_nonzero(z["flow"]).item() == 0
+    assert torch.max(torch.abs(z["flow"])).item() < 1e-5
 
 
 def test_preprocess_edge_cases(ops):
