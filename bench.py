@@ -134,12 +134,13 @@ def main():
             "target_reg": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
             "exclude_mask": torch.empty((B, N), dtype=torch.float32, device=dev),
         }
-        ring.append((scans, o0, o1, det, outs))
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, len(rr)), dtype=torch.uint8, device=dev)
+        ring.append((scans, o0, o1, det, outs, ws))
     want = ("flow", "target_cls", "target_reg", "exclude_mask")
 
     def step(i):
-        scans, o0, o1, det, outs = ring[i % a.ring]
-        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs)
+        scans, o0, o1, det, outs, ws = ring[i % a.ring]
+        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws)
 
     def barrier():
         torch.cuda.synchronize()
@@ -190,7 +191,7 @@ def main():
 
     # ---- parity of what was just computed (outside the timed region) ------------
     from oracle import ref_numpy as R
-    scans, o0, o1, det, outs = ring[0]
+    scans, o0, o1, det, outs, _ = ring[0]
     phi = R.laser_phi()
     flow = outs["flow"][:64].cpu().numpy()
     epe = 0.0
@@ -228,7 +229,7 @@ def main():
                        "launch": "hipGraph replay" if graph is not None else "eager",
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "epe_vs_oracle_m": epe,
-            "roofline": {"bound": "hbm", "kernel": "scan_preprocess_kernel<float,2>",
+            "roofline": {"bound": "hbm", "kernel": "scan_params_kernel + scan_preprocess_kernel<float,2>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms},

@@ -74,15 +74,21 @@ int pof_laser_phi(double angle_inc, int num_pts, double *tab /* [3*N] */, pof_st
  * target_cls    [B][N] int64;  target_reg [B][N][2] float32
  * dyn_mask, valid_mask, exclude_mask   [B][N] float32 in {0,1}
  * Any output pointer may be NULL.
+ * D             number of rows of det_rphi / det_cls (= det_offsets[B])
+ * workspace     device scratch of at least pof_scan_preprocess_workspace_bytes(B, D)
+ *               bytes: the per-sample rigid motion and per-detection cartesian
+ *               centres (a first, tiny launch) that the streaming launch reads
+ *               as wave-uniform scalars.
  * ---------------------------------------------------------------------- */
+size_t pof_scan_preprocess_workspace_bytes(int B, int D);
 int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,
                         const double *tab, const double *odom0, const double *odom1,
                         int flow_kind, int canonical, int out_f64, void *xy, void *flow,
                         const int32_t *det_offsets, const double *det_rphi, const uint8_t *det_cls,
-                        const double *assoc_radius, const int32_t *labels, const double *dyn_radius,
-                        int64_t *closest, int64_t *target_cls, float *target_reg,
-                        float *dyn_mask, float *valid_mask, float *exclude_mask,
-                        pof_stream_t stream);
+                        int D, const double *assoc_radius, const int32_t *labels,
+                        const double *dyn_radius, int64_t *closest, int64_t *target_cls,
+                        float *target_reg, float *dyn_mask, float *valid_mask, float *exclude_mask,
+                        void *workspace, size_t workspace_bytes, pof_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A4 stand-alone frame rotation of a flow field

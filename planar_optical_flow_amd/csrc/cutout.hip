@@ -5,24 +5,31 @@
 // Roofline: HBM, dominated by the output: (T*N*4 read + Ns*T*P*4 written) per
 // sample = 513 000 B at T=5, N=450, P=56.  The float64 index math (angle ->
 // fractional index -> floor/lerp) must round exactly like NumPy, so it stays in
-// float64 with contraction off; the gathers are served from LDS.
+// float64 with contraction off; at ~19 float64 instructions per output the VALU
+// time is of the same order as the HBM time, which is why the kernel is laid
+// out to make every per-window quantity wave-uniform:
 //
-// Two launches per call:
 //   1. cutout_area_kernel  (area_mode only) per-sample max window width ->
 //      s_area[b] = ceil(max/P) if any window covers more than P raw points, else 0
 //      (the reference takes this max over the whole (T,N) call, utils.py:304-308);
-//   2. cutout_kernel       one workgroup per (sample, tile of output points):
-//      phase A computes the per-(t,point) window parameters into LDS,
-//      phase B produces 4 consecutive cutout samples per thread (float4 stores,
-//      the tile's output region is one contiguous span).
+//   2. cutout_kernel       one workgroup per (sample, tile of 32 output points):
+//      phase A: one lane per window ((point,t) when `fixed`, point otherwise)
+//               computes the window table into LDS (correctly rounded float32
+//               half-angle, float64 start angle / step / clip bounds);
+//      phase B: one wave64 per window, lane = cutout sample k (P <= 64 lanes
+//               active; 64/P windows per wave when P <= 32).  Window parameters
+//               are LDS broadcasts, the lane's float64(k) is loop invariant, the
+//               range rows sit in LDS as (value, next-value - value) float2 so
+//               one ds_read_b64 feeds the lerp, and each wave stores P
+//               consecutive floats (the tile's output region is contiguous).
 #include "pof_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
+constexpr int kWaves = kThreads / 64;
 constexpr int kTileI = 32;          // output points per workgroup
 constexpr int kMaxT = 16;           // scans per window
-constexpr int kMaxPairs = kTileI * kMaxT;
 
 struct CutArgs {
     const float *scans;
@@ -33,11 +40,11 @@ struct CutArgs {
     float depth_f32;    // float32(window_depth)
     double depth;       // window_depth
     double rdepth;      // RN(1/window_depth)
+    int depth_pow2;     // 1/window_depth is exact: multiply instead of divide
     double padding;
     float *out;
     int32_t *s_area;
     int32_t *dbg_lo;
-    int rows_in_lds;    // 1: whole [T][N] sample staged in LDS
 };
 
 // Window of one (t, point): everything the reference derives from `dists`.
@@ -45,13 +52,11 @@ struct Window {
     double a0;   // phi_i - half_alpha                      (float64)
     float ha;    // half_alpha                              (float32)
     float da;    // 2*half_alpha/(P-1)                      (float32)
-    float d;     // the range that sizes the window         (float32)
 };
 
 __device__ __forceinline__ Window make_window(float d, double phi_i, float half_width, int P)
 {
     Window w;
-    w.d = d;
     float x = __fdiv_rn(half_width, fmaxf(d, 1e-2f));
     // correctly rounded float32 arctangent (float64 evaluation, rounded once)
     w.ha = (float)atan((double)x);
@@ -60,21 +65,23 @@ __device__ __forceinline__ Window make_window(float d, double phi_i, float half_
     return w;
 }
 
-__device__ __forceinline__ double frac_index(const Window &w, double step, int k, double phi0,
+// fractional scan index of cutout sample k: ((a0 + k*step) - phi0) / dphi
+__device__ __forceinline__ double frac_index(double a0, double step, double kd, double phi0,
                                              double dphi, double rdphi)
 {
-    double ang = w.a0 + (double)k * step;
+    double ang = a0 + kd * step;
     return pof_div_const(ang - phi0, dphi, rdphi);
 }
 
 __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
 {
-    __shared__ double s_max[kThreads / 64];
-    __shared__ int s_any[kThreads / 64];
+    __shared__ double s_max[kWaves];
+    __shared__ int s_any[kWaves];
     const int b = blockIdx.x;
     const float *smp = a.scans + (long long)b * a.T * a.N;
     const double phi0 = a.tab[0], dphi = a.tab[1] - a.tab[0], rdphi = 1.0 / dphi;
     const int rowsT = a.fixed ? a.T : 1;  // !fixed: every t has the same window
+    const double pm1 = (double)(a.P - 1);
     double mx = -1.0e300;
     int any = 0;
     for (int p = threadIdx.x; p < rowsT * a.Ns; p += kThreads) {
@@ -82,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
         const int i = (p % a.Ns) * a.stride;
         Window w = make_window(smp[t * a.N + i], a.tab[i], a.half_width, a.P);
         const double step = (double)w.da;
-        double width = frac_index(w, step, a.P - 1, phi0, dphi, rdphi) - frac_index(w, step, 0, phi0, dphi, rdphi);
+        double width = frac_index(w.a0, step, pm1, phi0, dphi, rdphi) - frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
         mx = fmax(mx, width);
         any |= width > (double)a.P;
     }
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int wv = 1; wv < kThreads / 64; ++wv) {
+        for (int wv = 1; wv < kWaves; ++wv) {
             mx = fmax(mx, s_max[wv]);
             any |= s_any[wv];
         }
@@ -102,17 +109,32 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
     }
 }
 
-template <bool VEC4, bool LDSROWS>
+// LDS window table: structure of arrays with `cap` entries each, carved from
+// dynamic LDS (cap = kTileI*T when `fixed`, kTileI otherwise).
+struct WinTable {
+    double *a0, *step, *lo_clip, *hi_clip, *dd, *step_a;
+    int *isarea;
+    __device__ WinTable(unsigned char *base, int cap)
+    {
+        a0 = reinterpret_cast<double *>(base);
+        step = a0 + cap;
+        lo_clip = step + cap;
+        hi_clip = lo_clip + cap;
+        dd = hi_clip + cap;
+        step_a = dd + cap;
+        isarea = reinterpret_cast<int *>(step_a + cap);
+    }
+};
+// bytes per entry, rounded so the rows that follow stay 16-byte aligned
+__host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 52 + 15) & ~(size_t)15; }
+
+template <bool LDSROWS>
 __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    // LDS: window table for the tile, then (optionally) the sample's rows
-    double *s_a0 = reinterpret_cast<double *>(smem);
-    float *s_da = reinterpret_cast<float *>(s_a0 + kMaxPairs);
-    float *s_d = s_da + kMaxPairs;
-    float *s_daa = s_d + kMaxPairs;
-    int *s_isarea = reinterpret_cast<int *>(s_daa + kMaxPairs);
-    float *s_rows = reinterpret_cast<float *>(s_isarea + kMaxPairs);
+    const int cap = a.fixed ? kTileI * a.T : kTileI;
+    WinTable wt(smem, cap);
+    float2 *s_rows = reinterpret_cast<float2 *>(smem + win_table_bytes(cap));  // [T][N] (value, delta)
 
     const int b = blockIdx.y;
     const int j0 = blockIdx.x * kTileI;
@@ -124,86 +146,103 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     const int PA = s_area * P;
 
     if (LDSROWS) {
-        for (int e = threadIdx.x; e < T * N; e += kThreads) s_rows[e] = smp[e];
-    }
-    // ---- phase A: window parameters of the tile's (point, t) pairs ----------
-    const int npairs = nj * T;
-    for (int p = threadIdx.x; p < npairs; p += kThreads) {
-        const int jj = p / T, t = p - jj * T;
-        const int i = (j0 + jj) * a.stride;
-        const float d = smp[(a.fixed ? t : T - 1) * N + i];
-        Window w = make_window(d, a.tab[i], a.half_width, P);
-        s_a0[p] = w.a0;
-        s_da[p] = w.da;
-        s_d[p] = d;
-        int isarea = 0;
-        float daa = 0.0f;
-        if (s_area > 0) {
-            const double step = (double)w.da;
-            double width = frac_index(w, step, P - 1, phi0, dphi, rdphi) - frac_index(w, step, 0, phi0, dphi, rdphi);
-            isarea = width > (double)P;
-            daa = __fdiv_rn(2.0f * w.ha, (float)(PA - 1));
+        for (int e = threadIdx.x; e < T * N; e += kThreads) {
+            const int i = e % N;
+            const float v = smp[e];
+            const float nx = (i + 1 < N) ? smp[e + 1] : v;   // hi index clamps to N-1
+            s_rows[e] = make_float2(v, nx - v);
         }
-        s_isarea[p] = isarea;
-        s_daa[p] = daa;
+    }
+    // ---- phase A: window table ------------------------------------------------
+    // fixed: one window per (point, t), entry jj*T + t;  else one per point, entry jj
+    const int nwin = a.fixed ? nj * T : nj;
+    for (int p = threadIdx.x; p < nwin; p += kThreads) {
+        const int jj = a.fixed ? p / T : p;
+        const int t = a.fixed ? p - jj * T : T - 1;
+        const int i = (j0 + jj) * a.stride;
+        const float d = smp[t * N + i];
+        Window w = make_window(d, a.tab[i], a.half_width, P);
+        const double step = (double)w.da;
+        wt.a0[p] = w.a0;
+        wt.step[p] = step;
+        wt.lo_clip[p] = (double)(d - a.depth_f32);
+        wt.hi_clip[p] = (double)(d + a.depth_f32);
+        wt.dd[p] = (double)d;
+        int isarea = 0;
+        double step_a = 0.0;
+        if (s_area > 0) {
+            double width = frac_index(w.a0, step, (double)(P - 1), phi0, dphi, rdphi) -
+                           frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
+            isarea = width > (double)P;
+            step_a = (double)__fdiv_rn(2.0f * w.ha, (float)(PA - 1));
+        }
+        wt.isarea[p] = isarea;
+        wt.step_a[p] = step_a;
     }
     __syncthreads();
 
+    // ---- phase B: one wave per window (or 64/P windows per wave) -----------------
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub_per_wave = (P <= 32) ? 64 / P : 1;      // windows handled side by side
+    const int sub = (P <= 32) ? lane / P : 0;
+    const bool sub_ok = sub < sub_per_wave;
     const double nm1 = (double)(N - 1);
-    constexpr int KV = VEC4 ? 4 : 1;
-    const int per_pair = P / KV;               // float4 groups per (point, t)
-    const int total = npairs * per_pair;
     float *out_tile = a.out + ((long long)b * a.Ns + j0) * T * P;
+    const int tcount = a.fixed ? 1 : T;
 
-    for (int g = threadIdx.x; g < total; g += kThreads) {
-        const int p = g / per_pair;
-        const int k0 = (g - p * per_pair) * KV;
-        const int jj = p / T, t = p - jj * T;
-        Window w;
-        w.a0 = s_a0[p];
-        w.da = s_da[p];
-        w.d = s_d[p];
-        const double step = (double)w.da;
-        const bool isarea = s_isarea[p] != 0;
-        const double step_a = (double)s_daa[p];
-        const double lo_clip = (double)(w.d - a.depth_f32), hi_clip = (double)(w.d + a.depth_f32);
-        float res[KV];
-#pragma unroll
-        for (int u = 0; u < KV; ++u) {
-            const int k = k0 + u;
-            const double idx = frac_index(w, step, k, phi0, dphi, rdphi);
-            const bool outb = (idx < 0.0) || (idx > nm1);
-            const double fl = fmin(fmax(floor(idx), 0.0), nm1);
-            const int lo = (int)fl;
-            const int hi = min(lo + 1, N - 1);
-            const double ratio = fmin(fmax(idx - fl, 0.0), 1.0);
-            const float vlo = LDSROWS ? s_rows[t * N + lo] : smp[t * N + lo];
-            const float vhi = LDSROWS ? s_rows[t * N + hi] : smp[t * N + hi];
-            double ct = (double)vlo + ratio * (double)(vhi - vlo);
-            if (isarea) {
-                // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
-                float acc = 0.0f;
-                for (int s = 0; s < s_area; ++s) {
-                    double ia = frac_index(w, step_a, k * s_area + s, phi0, dphi, rdphi);
-                    ia = rint(fmin(fmax(ia, 0.0), nm1));
-                    const float v = LDSROWS ? s_rows[t * N + (int)ia] : smp[t * N + (int)ia];
-                    acc = (s == 0) ? v : acc + v;
+    for (int kbase = 0; kbase < P; kbase += 64) {
+        const int k = (P <= 32) ? lane - sub * P : kbase + lane;
+        const bool k_ok = sub_ok && k < P;
+        const double kd = (double)k;
+        for (int p0 = wave * sub_per_wave; p0 < nwin; p0 += kWaves * sub_per_wave) {
+            const int p = p0 + sub;
+            if (!(k_ok && p < nwin)) continue;
+            const double a0 = wt.a0[p], step = wt.step[p];
+            const double lo_clip = wt.lo_clip[p], hi_clip = wt.hi_clip[p], dd = wt.dd[p];
+            const bool isarea = wt.isarea[p] != 0;
+            const double idx = frac_index(a0, step, kd, phi0, dphi, rdphi);
+            // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
+            const bool outb = (__double2hiint(idx) < 0) || (idx > nm1);
+            // in range: trunc == floor and idx - floor(idx) is exact; out of range the
+            // value is overwritten by the padding, only the LDS address must stay legal
+            const int lo = min(max((int)idx, 0), N - 1);
+            const double ratio = idx - floor(idx);
+            const int jj = a.fixed ? p / T : p;
+            const int tfirst = a.fixed ? p - jj * T : 0;
+            if (a.dbg_lo) {
+                for (int tt = 0; tt < tcount; ++tt)
+                    a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo;
+            }
+            for (int tt = 0; tt < tcount; ++tt) {
+                const int t = tfirst + tt;
+                float2 vd;
+                if (LDSROWS) {
+                    vd = s_rows[t * N + lo];
+                } else {
+                    const float v = smp[t * N + lo];
+                    vd = make_float2(v, smp[t * N + min(lo + 1, N - 1)] - v);
                 }
-                ct = (double)__fdiv_rn(acc, (float)s_area);
+                double ct = (double)vd.x + ratio * (double)vd.y;
+                if (isarea) {
+                    // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
+                    const double step_a = wt.step_a[p];
+                    float acc = 0.0f;
+                    for (int s = 0; s < s_area; ++s) {
+                        double ia = frac_index(a0, step_a, (double)(k * s_area + s), phi0, dphi, rdphi);
+                        ia = rint(fmin(fmax(ia, 0.0), nm1));
+                        const float v = LDSROWS ? s_rows[t * N + (int)ia].x : smp[t * N + (int)ia];
+                        acc = (s == 0) ? v : acc + v;
+                    }
+                    ct = (double)__fdiv_rn(acc, (float)s_area);
+                }
+                if (outb) ct = a.padding;
+                ct = fmin(fmax(ct, lo_clip), hi_clip);
+                if (a.centered) {
+                    ct = ct - dd;
+                    ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
+                }
+                out_tile[((long long)jj * T + t) * P + k] = (float)ct;
             }
-            if (outb) ct = a.padding;
-            ct = fmin(fmax(ct, lo_clip), hi_clip);
-            if (a.centered) {
-                ct = ct - (double)w.d;
-                ct = pof_div_const(ct, a.depth, a.rdepth);
-            }
-            res[u] = (float)ct;
-            if (a.dbg_lo) a.dbg_lo[(((long long)b * P + k) * T + t) * a.Ns + (j0 + jj)] = lo;
-        }
-        if (VEC4) {
-            reinterpret_cast<float4 *>(out_tile)[g] = make_float4(res[0], res[1], res[2], res[KV - 1]);
-        } else {
-            out_tile[g] = res[0];
         }
     }
 }
@@ -230,6 +269,10 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
     a.depth_f32 = (float)window_depth;
     a.depth = window_depth;
     a.rdepth = 1.0 / window_depth;
+    {
+        int e;
+        a.depth_pow2 = frexp(window_depth, &e) == 0.5;  // power of two: x/depth == x*(1/depth) exactly
+    }
     a.padding = padding_val;
     a.out = out; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
@@ -237,16 +280,13 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
         cutout_area_kernel<<<B, kThreads, 0, s>>>(a);
         POF_CHECK_LAUNCH();
     }
-    const size_t table_bytes = kMaxPairs * (sizeof(double) + 3 * sizeof(float) + sizeof(int));
-    const size_t row_bytes = (size_t)T * N * sizeof(float);
-    a.rows_in_lds = table_bytes + row_bytes <= 64 * 1024;
-    const size_t lds = table_bytes + (a.rows_in_lds ? row_bytes : 0);
+    const size_t row_bytes = (size_t)T * N * sizeof(float2);
+    const size_t tbl = win_table_bytes(fixed ? kTileI * T : kTileI);
+    const bool rows_in_lds = tbl + row_bytes <= 64 * 1024;
+    const size_t lds = tbl + (rows_in_lds ? row_bytes : 0);
     dim3 grid((a.Ns + kTileI - 1) / kTileI, B);
-    const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    if (vec4 && a.rows_in_lds) cutout_kernel<true, true><<<grid, kThreads, lds, s>>>(a);
-    else if (vec4) cutout_kernel<true, false><<<grid, kThreads, lds, s>>>(a);
-    else if (a.rows_in_lds) cutout_kernel<false, true><<<grid, kThreads, lds, s>>>(a);
-    else cutout_kernel<false, false><<<grid, kThreads, lds, s>>>(a);
+    if (rows_in_lds) cutout_kernel<true><<<grid, kThreads, lds, s>>>(a);
+    else cutout_kernel<false><<<grid, kThreads, lds, s>>>(a);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

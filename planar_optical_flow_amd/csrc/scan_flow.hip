@@ -11,6 +11,7 @@
 // Arithmetic is float64 (about 12 flop/point for the flow, 10 per detection for
 // the association): two orders of magnitude below the float64 vector peak at
 // the HBM rate, so nothing here is worth MFMA.
+#include <cmath>
 #include <type_traits>
 
 #include "pof_common.h"
@@ -18,7 +19,6 @@
 namespace {
 
 constexpr int kThreads = 256;
-constexpr int kDetTile = 64;  // detections staged in LDS per pass
 
 __global__ void laser_phi_kernel(double start, double stop, double step, int n, double *tab)
 {
@@ -38,7 +38,7 @@ __global__ void laser_phi_kernel(double start, double stop, double step, int n, 
 struct PreArgs {
     const float *ranges;
     long long sample_stride;
-    int B, N;
+    int B, N, D;
     const double *tab;
     const double *odom0, *odom1;
     int flow_kind, canonical;
@@ -46,54 +46,123 @@ struct PreArgs {
     const int32_t *det_offsets;
     const double *det_rphi;
     const uint8_t *det_cls;
-    double assoc_radius[3];
-    int32_t labels[3];
-    double dyn_radius[3];
+    double ra0, ra1, ra2;   // association radius per class
+    double sd0, sd1, sd2;   // max squared distance with RN(sqrt(s)) <= dynamic-mask radius
+    double sa0, sa1, sa2;   // max squared distance with RN(sqrt(s)) <  association radius
+    int32_t lb0, lb1, lb2;  // label per class
     int64_t *closest, *target_cls;
     float *target_reg, *dyn_mask, *valid_mask, *exclude_mask;
+    double *ws_rec;         // [B][kRecStride]: motion[7], detection count, kInline inline detections
+    double *ws_det;         // [D][6]: cx, cy, assoc radius, dyn s-threshold, label, assoc s-threshold
 };
 
-// Per-sample rigid motion, evaluated once per workgroup (lane 0) into LDS.
-// mot[0..3] = 2x2 matrix (row major), mot[4..5] = translation, mot[6] = dphi.
-__device__ void motion_params(int kind, const double *o0, const double *o1, double *mot)
+constexpr int kDetStride = 6;
+constexpr int kInline = 8;   // detections stored inline in the per-sample record
+constexpr int kRecStride = 8 + kInline * kDetStride;
+
+// Per-sample rigid motion from the two (sin, cos) pairs the params kernel
+// evaluates on two lanes.  mot[0..3] = 2x2 matrix (row major), mot[4..5] =
+// translation, mot[6] = dphi.
+//   kind 0: (sA,cA) = sincos(phi0), (sB,cB) = sincos(phi1)
+//   kind 1: (sA,cA) = sincos(phi0), (sB,cB) = sincos(phi1 - phi0)
+//   kind 2: (sB,cB) = sincos(phi1)
+__device__ void motion_params(int kind, const double *o0, const double *o1, double sA, double cA,
+                              double sB, double cB, double *mot)
 {
+    const double tx = o1[0] - o0[0], ty = o1[1] - o0[1];
     if (kind == 0) {
         // get_displacement_from_odometry: R0, R1 stored in float32; the float32
         // 2x2 product and the float64 products below use the FMA order of the
         // BLAS the reference calls (sgemm/dgemm/gemv: fma(a1, b1, a0*b0)).
-        float c0 = (float)cos(o0[2]), s0 = (float)sin(o0[2]);
-        float c1 = (float)cos(o1[2]), s1 = (float)sin(o1[2]);
+        const float c0 = (float)cA, s0 = (float)sA, c1 = (float)cB, s1 = (float)sB;
         // A = R0^T = [[c0, s0], [-s0, c0]],  R1 = [[c1, -s1], [s1, c1]]
-        float p00 = fmaf(s0, s1, c0 * c1);
-        float p01 = fmaf(s0, c1, c0 * (-s1));
-        float p10 = fmaf(c0, s1, (-s0) * c1);
-        float p11 = fmaf(c0, c1, (-s0) * (-s1));
+        const float p00 = fmaf(s0, s1, c0 * c1);
+        const float p01 = fmaf(s0, c1, c0 * (-s1));
+        const float p10 = fmaf(c0, s1, (-s0) * c1);
+        const float p11 = fmaf(c0, c1, (-s0) * (-s1));
         mot[0] = 1.0 - (double)p00;
         mot[1] = 0.0 - (double)p01;
         mot[2] = 0.0 - (double)p10;
         mot[3] = 1.0 - (double)p11;
-        double tx = o1[0] - o0[0], ty = o1[1] - o0[1];
         mot[4] = fma((double)c0, tx, (double)s0 * ty);
         mot[5] = fma((double)(-s0), tx, (double)c0 * ty);
+        mot[6] = 0.0;
     } else if (kind == 1) {
         // get_flow_target: float64 throughout
-        double s0, c0, s1, c1;
-        sincos(o0[2], &s0, &c0);
-        double dphi = o1[2] - o0[2];
-        sincos(dphi, &s1, &c1);
-        double tx = o1[0] - o0[0], ty = o1[1] - o0[1];
-        mot[0] = c1; mot[1] = -s1; mot[2] = s1; mot[3] = c1;
+        mot[0] = cB; mot[1] = -sB; mot[2] = sB; mot[3] = cB;
         // trans_world @ rot_0.T
-        mot[4] = fma(ty, -s0, tx * c0);
-        mot[5] = fma(ty, c0, tx * s0);
+        mot[4] = fma(ty, -sA, tx * cA);
+        mot[5] = fma(ty, cA, tx * sA);
+        mot[6] = 0.0;
     } else {
         // get_velocity_from_odometry: float32 R1, cross matrix dphi*[[0,-1],[1,0]]
-        float c1 = (float)cos(o1[2]), s1 = (float)sin(o1[2]);
-        double tx = o1[0] - o0[0], ty = o1[1] - o0[1];
+        const float c1 = (float)cB, s1 = (float)sB;
+        mot[0] = mot[1] = mot[2] = mot[3] = 0.0;
         mot[4] = fma((double)c1, tx, (double)s1 * ty);
         mot[5] = fma((double)(-s1), tx, (double)c1 * ty);
         mot[6] = o1[2] - o0[2];
     }
+}
+
+// Launch 1 (tiny): everything that needs a transcendental and is shared by all
+// points of a sample goes to the workspace, so that the streaming kernel below
+// is transcendental free and needs ONE memory round trip:
+//   ws_rec[b] = { rigid motion (7), detection count, first kInline detections }
+//   ws_det[g] = every detection (CSR order), read only by samples with more
+//               than kInline detections.
+// detection entry = { cx, cy, assoc radius, dyn s-threshold, label, assoc s-threshold }
+__device__ __forceinline__ void det_entry(const PreArgs &a, int g, double *w)
+{
+    const double dr = a.det_rphi[2 * g], dp = a.det_rphi[2 * g + 1];
+    double s, c;
+    sincos(dp, &s, &c);
+    const int cl = a.det_cls[g];
+    w[0] = dr * c;
+    w[1] = dr * s;
+    w[2] = cl == 0 ? a.ra0 : (cl == 1 ? a.ra1 : a.ra2);
+    w[3] = cl == 0 ? a.sd0 : (cl == 1 ? a.sd1 : a.sd2);   // dist <= dyn radius   <=>  s <= w[3]
+    w[4] = (double)(cl == 0 ? a.lb0 : (cl == 1 ? a.lb1 : a.lb2));
+    w[5] = cl == 0 ? a.sa0 : (cl == 1 ? a.sa1 : a.sa2);   // dist <  assoc radius <=>  s <= w[5]
+}
+
+__global__ __launch_bounds__(256) void scan_params_kernel(PreArgs a)
+{
+    // one sincos per lane: lanes [0, 2B) = (sample, angle) pairs, [2B, 2B+D) = CSR
+    // detections, then B*kInline inline detection slots
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nm = 2 * a.B;
+    if (t < nm) {
+        const int b = t >> 1, which = t & 1;
+        const double *o0 = a.odom0 + 3 * b, *o1 = a.odom1 + 3 * b;
+        double s = 0.0, c = 1.0;
+        if (a.flow) {
+            const double ang = which ? ((a.flow_kind == 1) ? o1[2] - o0[2] : o1[2]) : o0[2];
+            sincos(ang, &s, &c);
+        }
+        // partner lane (t ^ 1) holds the other angle of the same sample
+        const double s_o = __shfl_xor(s, 1, 64), c_o = __shfl_xor(c, 1, 64);
+        if (which == 0) {
+            double *rec = a.ws_rec + (long long)b * kRecStride;
+            if (a.flow) motion_params(a.flow_kind, o0, o1, s, c, s_o, c_o, rec);
+            rec[7] = a.det_offsets ? (double)(a.det_offsets[b + 1] - a.det_offsets[b]) : 0.0;
+        }
+    } else if (t < nm + a.D) {
+        const int g = t - nm;
+        det_entry(a, g, a.ws_det + (long long)g * kDetStride);
+    } else if (a.det_offsets && t < nm + a.D + a.B * kInline) {
+        const int u = t - nm - a.D;
+        const int b = u / kInline, slot = u - b * kInline;
+        const int d0 = a.det_offsets[b], d1 = a.det_offsets[b + 1];
+        if (slot < d1 - d0) det_entry(a, d0 + slot, a.ws_rec + (long long)b * kRecStride + 8 + slot * kDetStride);
+    }
+}
+
+// A value that is the same in every lane, moved to scalar registers.
+__device__ __forceinline__ double to_sgpr(double v)
+{
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
 
 template <typename OutT>
@@ -106,169 +175,311 @@ __device__ __forceinline__ void store2(OutT *base, long long idx, double a, doub
     reinterpret_cast<V *>(base)[idx] = v;
 }
 
-template <typename OutT, int PTS>
-__global__ __launch_bounds__(kThreads) void scan_preprocess_kernel(PreArgs a)
-{
-    __shared__ double s_mot[8];
-    __shared__ double s_cx[kDetTile], s_cy[kDetTile], s_dr[kDetTile], s_dphi[kDetTile];
-    __shared__ double s_ra[kDetTile], s_rd[kDetTile];
-    __shared__ int s_lab[kDetTile];
+// Launch 2: one workgroup per (SPB samples, 512-point chunk).  Each lane owns
+// the same PTS point indices in SPB consecutive samples, so the cos/sin entries
+// are loaded once and SPB range rows are in flight together.  Everything a
+// workgroup needs is requested up front (range rows, table, motions,
+// detections -> LDS): one memory round trip, then the association loop runs out
+// of LDS.  With SPB = 2 the 4096-sample batch is 2048 workgroups = one resident
+// wave of workgroups on 256 CUs.  PTS == 2: 16-byte stores throughout.
+constexpr int kDetTile = 32;
 
-    const int b = blockIdx.y;
+// float32 copy of a detection for the prefilter.  With |coordinates| < 100 m the
+// float32 squared distance is within 4.8e-5*sqrt(s) < 1e-3 + 1e-4*s of the
+// float64 one, so "s2f - mgn >= thr" / "s2f + mgn < thr" decide the float64
+// comparison; anything closer to a threshold, any far detection (thresholds set
+// to +inf / force exact) and every point inside the association disc take the
+// exact float64 path.
+__device__ __forceinline__ float4 prefilter_entry(double cx, double cy, double sd, double sa)
+{
+    const bool far = !(fabs(cx) + fabs(cy) < 100.0);
+    return make_float4((float)cx, (float)cy, (float)sd, far ? INFINITY : (float)sa);
+}
+
+template <typename OutT, int PTS, int SPB>
+__global__ __launch_bounds__(kThreads, 8) void scan_preprocess_kernel(PreArgs a)
+{
+    __shared__ double s_det[SPB][kDetTile][5];  // cx, cy, assoc radius, dyn s-threshold, assoc s-threshold
+    __shared__ int s_lab[SPB][kDetTile];
+    __shared__ float4 s_detf[SPB][kDetTile];    // float32 prefilter copy: cx, cy, dyn thr, assoc thr
+
+    const int b0 = blockIdx.y * SPB;
     const int tid = threadIdx.x;
     const int i0 = (blockIdx.x * kThreads + tid) * PTS;
     const int N = a.N;
+    const bool live = i0 < N;  // N % PTS == 0 is guaranteed by the launcher
     const bool want_flow = a.flow != nullptr;
     const bool want_assoc = a.det_offsets != nullptr;
 
-    if (want_flow && tid == 0) motion_params(a.flow_kind, a.odom0 + 3 * b, a.odom1 + 3 * b, s_mot);
-
-    // ---- load the points this thread owns ---------------------------------
-    float r[PTS];
-    double px[PTS], py[PTS], cs[PTS], sn[PTS];
-    const float *row = a.ranges + (long long)b * a.sample_stride;
-    const bool live = i0 < N;  // N % PTS == 0 is guaranteed by the launcher
-    if (live) {
-        if (PTS == 2) {
-            float2 v = *reinterpret_cast<const float2 *>(row + i0);
-            r[0] = v.x;
-            r[PTS - 1] = v.y;
-        } else {
-            r[0] = row[i0];
+    // ---- issue every load first ---------------------------------------------
+    int ndet[SPB];
+    float r[SPB][PTS];
+    double mot[SPB][7];
+#pragma unroll
+    for (int q = 0; q < SPB; ++q) {
+        const int b = min(b0 + q, a.B - 1);  // tail workgroup: clamp, stores are guarded
+        const float *row = a.ranges + (long long)b * a.sample_stride;
+#pragma unroll
+        for (int k = 0; k < PTS; ++k) r[q][k] = 0.0f;
+        if (live) {
+            if (PTS == 2) {
+                float2 v = *reinterpret_cast<const float2 *>(row + i0);
+                r[q][0] = v.x;
+                r[q][PTS - 1] = v.y;
+            } else {
+                r[q][0] = row[i0];
+            }
         }
+#pragma unroll
+        for (int c = 0; c < 7; ++c) mot[q][c] = 0.0;
+        ndet[q] = 0;
+        if (want_flow || want_assoc) {
+            // wave-uniform record written by the previous launch: constant address
+            // space -> scalar loads, the record lives in SGPRs
+            typedef const __attribute__((address_space(4))) double *cptr;
+            cptr m = (cptr)(a.ws_rec + (long long)b * kRecStride);
+#pragma unroll
+            for (int c = 0; c < 7; ++c) mot[q][c] = m[c];
+            ndet[q] = (int)m[7];
+        }
+    }
+    double cs[PTS], sn[PTS];
+#pragma unroll
+    for (int k = 0; k < PTS; ++k) cs[k] = sn[k] = 0.0;
+    if (live) {
 #pragma unroll
         for (int k = 0; k < PTS; ++k) {
             double2 t = *reinterpret_cast<const double2 *>(a.tab + N + 2 * (i0 + k));
             cs[k] = t.x;
             sn[k] = t.y;
-            px[k] = (double)r[k] * cs[k];
-            py[k] = (double)r[k] * sn[k];
         }
     }
-    const long long o = (long long)b * N + i0;  // flat point index of the first owned point
-
-    if (live && a.xy) {
-        OutT *xy = static_cast<OutT *>(a.xy);
-#pragma unroll
-        for (int k = 0; k < PTS; ++k) store2<OutT>(xy, o + k, px[k], py[k]);
-    }
-
-    __syncthreads();
-
-    // ---- rigid-motion flow -------------------------------------------------
-    if (live && want_flow) {
-        OutT *fl = static_cast<OutT *>(a.flow);
-#pragma unroll
-        for (int k = 0; k < PTS; ++k) {
-            double fx, fy;
-            if (a.flow_kind == 0) {
-                fx = fma(py[k], s_mot[1], px[k] * s_mot[0]) - s_mot[4];
-                fy = fma(py[k], s_mot[3], px[k] * s_mot[2]) - s_mot[5];
-            } else if (a.flow_kind == 1) {
-                double x1 = fma(py[k], s_mot[1], px[k] * s_mot[0]) - s_mot[4];
-                double y1 = fma(py[k], s_mot[3], px[k] * s_mot[2]) - s_mot[5];
-                fx = x1 - px[k];
-                fy = y1 - py[k];
-            } else {
-                // -lin - xy @ cross^T, cross^T = [[0, dphi], [-dphi, 0]]
-                fx = -s_mot[4] - (py[k] * -s_mot[6]);
-                fy = -s_mot[5] - (px[k] * s_mot[6]);
-            }
-            if (a.canonical) {
-                // einsum('ijk,ik->ij'): c*fx + (-s)*fy ; s*fx + c*fy, no fusion
-                double gx = cs[k] * fx + (-sn[k]) * fy;
-                double gy = sn[k] * fx + cs[k] * fy;
-                fx = gx;
-                fy = gy;
-            }
-            store2<OutT>(fl, o + k, fx, fy);
-        }
-    }
-
-    // ---- valid mask (needs no detections) ----------------------------------
-    float vmask[PTS], dmask[PTS];
-#pragma unroll
-    for (int k = 0; k < PTS; ++k) {
-        vmask[k] = (live && r[k] >= 20.0f) ? 0.0f : 1.0f;
-        dmask[k] = 1.0f;
-    }
-
-    // ---- association + dynamic mask ----------------------------------------
     if (want_assoc) {
-        const int d0 = a.det_offsets[b], d1 = a.det_offsets[b + 1];
-        double best[PTS];
-        int bidx[PTS];
+        // inline detections of every sample -> LDS; the address depends on the sample
+        // index only, so these loads fly together with the range rows (lanes that map
+        // to slots past the sample's count stage unused values)
+        const int qsel = tid / kInline, j = tid - qsel * kInline;
+#pragma unroll
+        for (int q = 0; q < SPB; ++q) {
+            if (qsel == q) {
+                const int b = min(b0 + q, a.B - 1);
+                const double *w = a.ws_rec + (long long)b * kRecStride + 8 + j * kDetStride;
+                s_det[q][j][0] = w[0];
+                s_det[q][j][1] = w[1];
+                s_det[q][j][2] = w[2];
+                s_det[q][j][3] = w[3];
+                s_det[q][j][4] = w[5];
+                s_lab[q][j] = (int)w[4];
+                s_detf[q][j] = prefilter_entry(w[0], w[1], w[3], w[5]);
+            }
+        }
+    }
+    bool synced = false;
+
+#pragma unroll
+    for (int q = 0; q < SPB; ++q) {
+        const int b = b0 + q;
+        const bool ok = live && b < a.B;
+        double px[PTS], py[PTS];
 #pragma unroll
         for (int k = 0; k < PTS; ++k) {
-            best[k] = 0.0;  // the prepended zero column
-            bidx[k] = 0;
+            px[k] = (double)r[q][k] * cs[k];
+            py[k] = (double)r[q][k] * sn[k];
         }
-        for (int base = d0; base < d1; base += kDetTile) {
-            const int cnt = min(kDetTile, d1 - base);
-            __syncthreads();
-            if (tid < cnt) {
-                double dr = a.det_rphi[2 * (base + tid)], dp = a.det_rphi[2 * (base + tid) + 1];
-                double s, c;
-                sincos(dp, &s, &c);
-                int cl = a.det_cls[base + tid];
-                cl = cl > 2 ? 2 : cl;
-                s_cx[tid] = dr * c;
-                s_cy[tid] = dr * s;
-                s_dr[tid] = dr;
-                s_dphi[tid] = dp;
-                s_ra[tid] = a.assoc_radius[cl];
-                s_rd[tid] = a.dyn_radius[cl];
-                s_lab[tid] = a.labels[cl];
+        float pxf[PTS], pyf[PTS];
+        bool far[PTS];
+#pragma unroll
+        for (int k = 0; k < PTS; ++k) {
+            pxf[k] = (float)px[k];
+            pyf[k] = (float)py[k];
+            far[k] = !(fabsf(pxf[k]) + fabsf(pyf[k]) < 100.0f);  // margin analysis assumes < 100 m (NaN -> exact)
+        }
+        const long long o = (long long)b * N + i0;  // flat point index of the first owned point
+
+        if (ok && a.xy) {
+            OutT *xy = static_cast<OutT *>(a.xy);
+#pragma unroll
+            for (int k = 0; k < PTS; ++k) store2<OutT>(xy, o + k, px[k], py[k]);
+        }
+
+        // ---- rigid-motion flow ---------------------------------------------
+        if (ok && want_flow) {
+            OutT *fl = static_cast<OutT *>(a.flow);
+            const double m0 = mot[q][0], m1 = mot[q][1], m2 = mot[q][2], m3 = mot[q][3];
+            const double t0 = mot[q][4], t1 = mot[q][5], dph = mot[q][6];
+            double fxs[PTS], fys[PTS];
+#pragma unroll
+            for (int k = 0; k < PTS; ++k) {
+                double fx, fy;
+                if (a.flow_kind == 0) {
+                    fx = fma(py[k], m1, px[k] * m0) - t0;
+                    fy = fma(py[k], m3, px[k] * m2) - t1;
+                } else if (a.flow_kind == 1) {
+                    double x1 = fma(py[k], m1, px[k] * m0) - t0;
+                    double y1 = fma(py[k], m3, px[k] * m2) - t1;
+                    fx = x1 - px[k];
+                    fy = y1 - py[k];
+                } else {
+                    // -lin - xy @ cross^T, cross^T = [[0, dphi], [-dphi, 0]]
+                    fx = -t0 - (py[k] * -dph);
+                    fy = -t1 - (px[k] * dph);
+                }
+                if (a.canonical) {
+                    // einsum('ijk,ik->ij'): c*fx + (-s)*fy ; s*fx + c*fy, no fusion
+                    double gx = cs[k] * fx + (-sn[k]) * fy;
+                    double gy = sn[k] * fx + cs[k] * fy;
+                    fx = gx;
+                    fy = gy;
+                }
+                fxs[k] = fx;
+                fys[k] = fy;
             }
-            __syncthreads();
-            if (live) {
+            if (PTS == 2 && sizeof(OutT) == 4) {
+                reinterpret_cast<float4 *>(fl)[o / 2] =
+                    make_float4((float)fxs[0], (float)fys[0], (float)fxs[PTS - 1], (float)fys[PTS - 1]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < PTS; ++k) store2<OutT>(fl, o + k, fxs[k], fys[k]);
+            }
+        }
+
+        float vmask[PTS], dmask[PTS];
+#pragma unroll
+        for (int k = 0; k < PTS; ++k) {
+            vmask[k] = (r[q][k] >= 20.0f) ? 0.0f : 1.0f;
+            dmask[k] = 1.0f;
+        }
+
+        // ---- association + dynamic mask ------------------------------------
+        if (want_assoc) {
+            double best[PTS];
+            int bidx[PTS];
+#pragma unroll
+            for (int k = 0; k < PTS; ++k) {
+                best[k] = 0.0;  // the prepended zero column
+                bidx[k] = 0;
+            }
+            if (!synced) {
+                __syncthreads();  // first tiles of all SPB samples are in LDS
+                synced = true;
+            }
+            // tile 0 = the inline detections; further tiles (crowded samples only) come
+            // from the CSR table through the same LDS buffer
+            int dfirst = 0;
+            if (ndet[q] > kInline) dfirst = a.det_offsets[min(b, a.B - 1)];
+            for (int base = 0; base < ndet[q]; base += (base == 0 ? kInline : kDetTile)) {
+                const int cnt = min(base == 0 ? kInline : kDetTile, ndet[q] - base);
+                if (base != 0) {
+                    __syncthreads();
+                    if (tid < cnt) {
+                        const double *w = a.ws_det + (long long)(dfirst + base + tid) * kDetStride;
+                        s_det[q][tid][0] = w[0];
+                        s_det[q][tid][1] = w[1];
+                        s_det[q][tid][2] = w[2];
+                        s_det[q][tid][3] = w[3];
+                        s_det[q][tid][4] = w[5];
+                        s_lab[q][tid] = (int)w[4];
+                        s_detf[q][tid] = prefilter_entry(w[0], w[1], w[3], w[5]);
+                    }
+                    __syncthreads();
+                }
+                float4 fnext = s_detf[q][0];
                 for (int j = 0; j < cnt; ++j) {
-                    const double cx = s_cx[j], cy = s_cy[j], ra = s_ra[j], rd = s_rd[j];
+                    // float32 prefilter with a conservative margin: the exact float64
+                    // test below runs only for lanes it cannot classify (inside the
+                    // association disc, or within the margin of a threshold)
+                    const float4 f = fnext;
+                    fnext = s_detf[q][min(j + 1, kDetTile - 1)];  // next entry in flight during this one
+                    bool exact[PTS];
+                    bool any_exact = false;
 #pragma unroll
                     for (int k = 0; k < PTS; ++k) {
-                        double ex = px[k] - cx, ey = py[k] - cy;
-                        double dist = sqrt(ex * ex + ey * ey);
-                        double v = dist - ra;
-                        if (v < best[k]) {
-                            best[k] = v;
-                            bidx[k] = base - d0 + j + 1;
+                        const float exf = pxf[k] - f.x, eyf = pyf[k] - f.y;
+                        const float s2f = fmaf(exf, exf, eyf * eyf);
+                        const float mgn = fmaf(s2f, 1e-4f, 1e-3f);
+                        exact[k] = far[k] || (s2f - mgn < f.w) || (fabsf(s2f - f.z) <= mgn);
+                        if (!exact[k] && s2f < f.z) dmask[k] = 0.0f;   // surely within the dyn radius
+                        any_exact |= exact[k];
+                    }
+                    if (any_exact) {
+                        const double cx = s_det[q][j][0], cy = s_det[q][j][1];
+                        const double sd = s_det[q][j][3], sa = s_det[q][j][4];
+#pragma unroll
+                        for (int k = 0; k < PTS; ++k) {
+                            if (!exact[k]) continue;
+                            const double ex = px[k] - cx, ey = py[k] - cy;
+                            const double s2 = ex * ex + ey * ey;   // cdist: (dx*dx) + (dy*dy), no fusion
+                            if (s2 <= sd) dmask[k] = 0.0f;         // dist <= dyn radius
+                            if (s2 <= sa) {                        // dist < assoc radius: the only case that can win
+                                const double v = sqrt(s2) - s_det[q][j][2];
+                                if (v < best[k]) {
+                                    best[k] = v;
+                                    bidx[k] = base + j + 1;
+                                }
+                            }
                         }
-                        if (dist <= rd) dmask[k] = 0.0f;
                     }
                 }
             }
-        }
-        if (live) {
+            if (ok) {
+                long long cls[PTS];
+                float gx[PTS], gy[PTS];
 #pragma unroll
-            for (int k = 0; k < PTS; ++k) {
-                if (a.closest) a.closest[o + k] = bidx[k];
-                long long cls = 0;
-                float gx = 0.0f, gy = 0.0f;
-                if (bidx[k] > 0) {
-                    // re-read the winning detection (rare path: a few % of points)
-                    const int g = d0 + bidx[k] - 1;
-                    const double dr = a.det_rphi[2 * g], dp = a.det_rphi[2 * g + 1];
-                    int cl = a.det_cls[g];
-                    cl = cl > 2 ? 2 : cl;
-                    cls = a.labels[cl];
-                    const double phi = a.tab[i0 + k];
-                    double s, c;
-                    sincos(dp - phi, &s, &c);
-                    gx = (float)(s * dr);
-                    gy = (float)(c * dr - (double)r[k]);
+                for (int k = 0; k < PTS; ++k) {
+                    cls[k] = 0;
+                    gx[k] = gy[k] = 0.0f;
+                    if (bidx[k] > 0) {
+                        // winner's centre and label: still in LDS unless the sample overflowed
+                        // the inline tile (then from the CSR table).  global_to_canonical via the
+                        // angle-difference identity: sin(dp-phi)*dr = cy*cos(phi) - cx*sin(phi)
+                        double wx, wy;
+                        if (ndet[q] <= kInline) {
+                            wx = s_det[q][bidx[k] - 1][0];
+                            wy = s_det[q][bidx[k] - 1][1];
+                            cls[k] = s_lab[q][bidx[k] - 1];
+                        } else {
+                            const double *w = a.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
+                            wx = w[0];
+                            wy = w[1];
+                            cls[k] = (long long)w[4];
+                        }
+                        gx[k] = (float)(wy * cs[k] - wx * sn[k]);
+                        gy[k] = (float)((wx * cs[k] + wy * sn[k]) - (double)r[q][k]);
+                    }
                 }
-                if (a.target_cls) a.target_cls[o + k] = cls;
-                if (a.target_reg) reinterpret_cast<float2 *>(a.target_reg)[o + k] = make_float2(gx, gy);
+                if (PTS == 2) {
+                    using LL2 = long long __attribute__((ext_vector_type(2)));
+                    if (a.closest) {
+                        LL2 v = {bidx[0], bidx[PTS - 1]};
+                        reinterpret_cast<LL2 *>(a.closest)[o / 2] = v;
+                    }
+                    if (a.target_cls) {
+                        LL2 v = {cls[0], cls[PTS - 1]};
+                        reinterpret_cast<LL2 *>(a.target_cls)[o / 2] = v;
+                    }
+                    if (a.target_reg)
+                        reinterpret_cast<float4 *>(a.target_reg)[o / 2] =
+                            make_float4(gx[0], gy[0], gx[PTS - 1], gy[PTS - 1]);
+                } else {
+                    if (a.closest) a.closest[o] = bidx[0];
+                    if (a.target_cls) a.target_cls[o] = cls[0];
+                    if (a.target_reg) reinterpret_cast<float2 *>(a.target_reg)[o] = make_float2(gx[0], gy[0]);
+                }
             }
         }
-    }
 
-    if (live) {
-#pragma unroll
-        for (int k = 0; k < PTS; ++k) {
-            if (a.dyn_mask) a.dyn_mask[o + k] = dmask[k];
-            if (a.valid_mask) a.valid_mask[o + k] = vmask[k];
-            if (a.exclude_mask) a.exclude_mask[o + k] = dmask[k] * vmask[k];
+        if (ok) {
+            if (PTS == 2) {
+                if (a.dyn_mask) reinterpret_cast<float2 *>(a.dyn_mask)[o / 2] = make_float2(dmask[0], dmask[PTS - 1]);
+                if (a.valid_mask) reinterpret_cast<float2 *>(a.valid_mask)[o / 2] = make_float2(vmask[0], vmask[PTS - 1]);
+                if (a.exclude_mask)
+                    reinterpret_cast<float2 *>(a.exclude_mask)[o / 2] =
+                        make_float2(dmask[0] * vmask[0], dmask[PTS - 1] * vmask[PTS - 1]);
+            } else {
+                if (a.dyn_mask) a.dyn_mask[o] = dmask[0];
+                if (a.valid_mask) a.valid_mask[o] = vmask[0];
+                if (a.exclude_mask) a.exclude_mask[o] = dmask[0] * vmask[0];
+            }
         }
     }
 }
@@ -336,44 +547,99 @@ extern "C" int pof_laser_phi(double angle_inc, int num_pts, double *tab, pof_str
     return POF_OK;
 }
 
+// Largest float64 s with RN(sqrt(s)) <= r (strict = false) or < r (strict = true).
+// sqrt is monotone and correctly rounded (IEEE, host libm), so comparing the
+// SQUARED distance with this threshold decides "dist <= r" / "dist < r" exactly
+// as the reference does on the rounded distance -- without a square root per point.
+static double sq_threshold(double r, bool strict)
+{
+    if (!(r > 0.0)) return (!strict && r == 0.0) ? 0.0 : -1.0;
+    auto ok = [&](double s) { double q = std::sqrt(s); return strict ? (q < r) : (q <= r); };
+    double c = r * r;
+    for (int it = 0; it < 64 && !ok(c); ++it) c = std::nextafter(c, 0.0);
+    for (int it = 0; it < 64; ++it) {
+        double up = std::nextafter(c, HUGE_VAL);
+        if (!ok(up)) break;
+        c = up;
+    }
+    return c;
+}
+
+extern "C" size_t pof_scan_preprocess_workspace_bytes(int B, int D)
+{
+    if (B < 0 || D < 0) return 0;
+    return ((size_t)B * kRecStride + (size_t)D * kDetStride) * sizeof(double) + 64;
+}
+
 extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,
                                    const double *tab, const double *odom0, const double *odom1,
                                    int flow_kind, int canonical, int out_f64, void *xy, void *flow,
                                    const int32_t *det_offsets, const double *det_rphi,
-                                   const uint8_t *det_cls, const double *assoc_radius,
+                                   const uint8_t *det_cls, int D, const double *assoc_radius,
                                    const int32_t *labels, const double *dyn_radius, int64_t *closest,
                                    int64_t *target_cls, float *target_reg, float *dyn_mask,
-                                   float *valid_mask, float *exclude_mask, pof_stream_t stream)
+                                   float *valid_mask, float *exclude_mask, void *workspace,
+                                   size_t workspace_bytes, pof_stream_t stream)
 {
-    if (!ranges || !tab || B < 0 || N < 1) return POF_E_BADARG;
+    if (!ranges || !tab || B < 0 || N < 1 || D < 0) return POF_E_BADARG;
     if (flow && (!odom0 || !odom1)) return POF_E_BADARG;
     if (flow_kind < 0 || flow_kind > 2) return POF_E_BADARG;
     if (det_offsets && (!assoc_radius || !labels || !dyn_radius)) return POF_E_BADARG;
+    if (det_offsets && D > 0 && (!det_rphi || !det_cls)) return POF_E_BADARG;
     if (sample_stride < N) return POF_E_SHAPE;
     if (B == 0) return POF_OK;
     if (B > 65535) return POF_E_SHAPE;  // grid.y limit; callers chunk larger batches
+    const bool need_ws = flow || det_offsets;
+    if (need_ws && (!workspace || workspace_bytes < pof_scan_preprocess_workspace_bytes(B, det_offsets ? D : 0)))
+        return POF_E_WORKSPACE;
     PreArgs a;
-    a.ranges = ranges; a.sample_stride = sample_stride; a.B = B; a.N = N; a.tab = tab;
+    a.ranges = ranges; a.sample_stride = sample_stride; a.B = B; a.N = N; a.D = det_offsets ? D : 0;
+    a.tab = tab;
     a.odom0 = odom0; a.odom1 = odom1; a.flow_kind = flow_kind; a.canonical = canonical;
     a.xy = xy; a.flow = flow; a.det_offsets = det_offsets; a.det_rphi = det_rphi; a.det_cls = det_cls;
-    for (int k = 0; k < 3; ++k) {
-        a.assoc_radius[k] = det_offsets ? assoc_radius[k] : 0.0;
-        a.labels[k] = det_offsets ? labels[k] : 0;
-        a.dyn_radius[k] = det_offsets ? dyn_radius[k] : 0.0;
-    }
+    a.ra0 = det_offsets ? assoc_radius[0] : 0.0; a.ra1 = det_offsets ? assoc_radius[1] : 0.0;
+    a.ra2 = det_offsets ? assoc_radius[2] : 0.0;
+    double thr[6] = {0, 0, 0, 0, 0, 0};
+    if (det_offsets)
+        for (int k = 0; k < 3; ++k) {
+            thr[k] = sq_threshold(dyn_radius[k], false);
+            thr[3 + k] = sq_threshold(assoc_radius[k], true);
+        }
+    a.sd0 = thr[0]; a.sd1 = thr[1]; a.sd2 = thr[2];
+    a.sa0 = thr[3]; a.sa1 = thr[4]; a.sa2 = thr[5];
+    a.lb0 = det_offsets ? labels[0] : 0; a.lb1 = det_offsets ? labels[1] : 0; a.lb2 = det_offsets ? labels[2] : 0;
     a.closest = closest; a.target_cls = target_cls; a.target_reg = target_reg;
     a.dyn_mask = dyn_mask; a.valid_mask = valid_mask; a.exclude_mask = exclude_mask;
-    // float2 row loads need 8-byte aligned rows
-    const bool vec2 = (N % 2 == 0) && (sample_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(ranges) & 7) == 0);
+    // workspace: 64-byte aligned motion block, then the detection block
+    uintptr_t base = (reinterpret_cast<uintptr_t>(workspace) + 63) & ~(uintptr_t)63;
+    a.ws_rec = reinterpret_cast<double *>(base);
+    a.ws_det = a.ws_rec + (size_t)B * kRecStride;
     hipStream_t s = pof_stream(stream);
+    if (need_ws) {
+        const int total = 2 * B + a.D + (det_offsets ? B * kInline : 0);
+        scan_params_kernel<<<(total + 255) / 256, 256, 0, s>>>(a);
+        POF_CHECK_LAUNCH();
+    }
+    // float2 row loads need 8-byte aligned rows
+    auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const bool vec2 = (N % 2 == 0) && (sample_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(ranges) & 7) == 0) &&
+                      al16(xy) && al16(flow) && al16(closest) && al16(target_cls) && al16(target_reg) &&
+                      al16(dyn_mask) && al16(valid_mask) && al16(exclude_mask);
+    // two samples per workgroup once the batch alone fills the chip
+    const bool spb2 = B >= 2048;
     if (vec2) {
-        dim3 grid((N / 2 + kThreads - 1) / kThreads, B);
-        if (out_f64) scan_preprocess_kernel<double, 2><<<grid, kThreads, 0, s>>>(a);
-        else scan_preprocess_kernel<float, 2><<<grid, kThreads, 0, s>>>(a);
+        dim3 grid((N / 2 + kThreads - 1) / kThreads, spb2 ? (B + 1) / 2 : B);
+        if (spb2) {
+            if (out_f64) scan_preprocess_kernel<double, 2, 2><<<grid, kThreads, 0, s>>>(a);
+            else scan_preprocess_kernel<float, 2, 2><<<grid, kThreads, 0, s>>>(a);
+        } else {
+            if (out_f64) scan_preprocess_kernel<double, 2, 1><<<grid, kThreads, 0, s>>>(a);
+            else scan_preprocess_kernel<float, 2, 1><<<grid, kThreads, 0, s>>>(a);
+        }
     } else {
         dim3 grid((N + kThreads - 1) / kThreads, B);
-        if (out_f64) scan_preprocess_kernel<double, 1><<<grid, kThreads, 0, s>>>(a);
-        else scan_preprocess_kernel<float, 1><<<grid, kThreads, 0, s>>>(a);
+        if (out_f64) scan_preprocess_kernel<double, 1, 1><<<grid, kThreads, 0, s>>>(a);
+        else scan_preprocess_kernel<float, 1, 1><<<grid, kThreads, 0, s>>>(a);
     }
     POF_CHECK_LAUNCH();
     return POF_OK;

@@ -83,10 +83,14 @@ class DetCSR:
 FLOW_DISPLACEMENT, FLOW_TARGET, FLOW_VELOCITY = 0, 1, 2
 
 
+def scan_preprocess_workspace_bytes(B, D):
+    return int(_lib.load().pof_scan_preprocess_workspace_bytes(int(min(B, 65535)), int(D)))
+
+
 def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLOW_DISPLACEMENT,
                     canonical=True, out_dtype=torch.float32, want=("flow",),
                     assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3), dyn_radius=(2.5, 2.0, 2.0),
-                    out=None):
+                    out=None, workspace=None):
     """A2-A7 fused, one launch.
 
     scans: [B,T,N] (the last row of each window is the current scan) or [B,N].
@@ -150,6 +154,12 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
     lb = (C.c_int32 * 3)(*labels)
     dr = (C.c_double * 3)(*dyn_radius)
     base = scans.data_ptr() + 4 * off
+    D = int(dets.rphi.shape[0]) if need_det else 0
+    ws_bytes = _lib.load().pof_scan_preprocess_workspace_bytes(min(B, 65535), D)
+    if workspace is None:
+        workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    elif workspace.numel() * workspace.element_size() < ws_bytes or not workspace.is_cuda:
+        raise ValueError("workspace must be a device tensor of at least %d bytes" % ws_bytes)
     with torch.cuda.device(dev):
         # grid.y carries the sample index: chunk very large batches
         step = 65535
@@ -167,9 +177,9 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
                 int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
                 sl(xy, 2 * N), sl(flow, 2 * N),
                 sl(dets.offsets, 1) if need_det else None,
-                _ptr(dets.rphi) if need_det else None, _ptr(dets.cls) if need_det else None,
+                _ptr(dets.rphi) if need_det else None, _ptr(dets.cls) if need_det else None, D,
                 ar, lb, dr, sl(closest, N), sl(tcls, N), sl(treg, 2 * N), sl(dyn, N), sl(val, N),
-                sl(exc, N), _stream())
+                sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(), _stream())
     return out
 
 
