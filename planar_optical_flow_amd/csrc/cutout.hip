@@ -12,28 +12,29 @@
 //   1. cutout_area_kernel  (area_mode only) per-sample max window width ->
 //      s_area[b] = ceil(max/P) if any window covers more than P raw points, else 0
 //      (the reference takes this max over the whole (T,N) call, utils.py:304-308);
-//   2. cutout_kernel       one workgroup per (sample, tile of 32 output points):
+//   2. cutout_kernel       one workgroup per (sample, tile of ~256/T output points):
 //      phase A: one lane per window ((point,t) when `fixed`, point otherwise)
 //               computes the window table into LDS (correctly rounded float32
 //               half-angle, float64 start angle / step / clip bounds);
-//      phase B: one wave64 per window, lane = cutout sample k (P <= 64 lanes
-//               active; 64/P windows per wave when P <= 32).  Window parameters
-//               are LDS broadcasts, the lane's float64(k) is loop invariant, the
-//               range rows sit in LDS as (value, next-value - value) float2 so
-//               one ds_read_b64 feeds the lerp, and each wave stores P
-//               consecutive floats (the tile's output region is contiguous).
+//      phase B: every lane produces 4 consecutive cutout samples of one window
+//               (one float4 store; the tile's output region is one contiguous
+//               span).  The window parameters are read from LDS once per 4
+//               outputs, the range rows sit in LDS (loaded into registers at
+//               kernel entry, their latency hidden behind phase A), floor/ratio
+//               use trunc + v_fract (exact in range), np.clip is compare + select.
 #include "pof_common.h"
 
 namespace {
 
 constexpr int kThreads = 256;
 constexpr int kWaves = kThreads / 64;
-constexpr int kTileI = 32;          // output points per workgroup
+constexpr int kMaxWin = 256;        // window-table entries per workgroup (phase A: one lane each)
 constexpr int kMaxT = 16;           // scans per window
 
 struct CutArgs {
     const float *scans;
     int B, T, N, Ns, stride;
+    int tile;           // output points per workgroup
     const double *tab;
     int centered, fixed, P, area_mode;
     float half_width;   // float32(0.5 * window_width)
@@ -110,10 +111,10 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
 }
 
 // LDS window table: structure of arrays with `cap` entries each, carved from
-// dynamic LDS (cap = kTileI*T when `fixed`, kTileI otherwise).
+// dynamic LDS (cap = tile*T when `fixed`, tile otherwise; <= kMaxWin).
 struct WinTable {
     double *a0, *step, *lo_clip, *hi_clip, *dd, *step_a;
-    int *isarea;
+    int *isarea, *out_off, *row_off;
     __device__ WinTable(unsigned char *base, int cap)
     {
         a0 = reinterpret_cast<double *>(base);
@@ -123,34 +124,52 @@ struct WinTable {
         dd = hi_clip + cap;
         step_a = dd + cap;
         isarea = reinterpret_cast<int *>(step_a + cap);
+        out_off = isarea + cap;
+        row_off = out_off + cap;
     }
 };
-// bytes per entry, rounded so the rows that follow stay 16-byte aligned
-__host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 52 + 15) & ~(size_t)15; }
+// bytes per entry (6 doubles + 3 ints), rounded so the rows that follow stay 16-byte aligned
+__host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 60 + 15) & ~(size_t)15; }
 
-template <bool LDSROWS>
+// One workgroup = one sample x `tile` output points.
+//   LDSROWS  the sample's [T][N] rows are staged in LDS as (value, next - value)
+//   P4       P/4 when it is a compile-time constant (14, 12, 8): the lane ->
+//            (window, k-group) split is then a multiply, and every lane produces
+//            4 consecutive cutout samples -> one float4 store;  0: same with a
+//            runtime P/4;  -1: P % 4 != 0, one sample per lane.
+//   FAST     centred output with a power-of-two depth (the configs of the
+//            reference): (ct - d) * (1/depth) without the generic-divisor code
+//   DBG      also write the inds_ct_low debug tensor (tests only)
+template <bool LDSROWS, int P4, bool FAST, bool DBG>
 __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int cap = a.fixed ? kTileI * a.T : kTileI;
+    const int cap = a.fixed ? a.tile * a.T : a.tile;
     WinTable wt(smem, cap);
-    float2 *s_rows = reinterpret_cast<float2 *>(smem + win_table_bytes(cap));  // [T][N] (value, delta)
+    float *s_rows = reinterpret_cast<float *>(smem + win_table_bytes(cap));  // [T][N] range rows
 
     const int b = blockIdx.y;
-    const int j0 = blockIdx.x * kTileI;
-    const int nj = min(kTileI, a.Ns - j0);
+    const int j0 = blockIdx.x * a.tile;
+    const int nj = min(a.tile, a.Ns - j0);
     const int T = a.T, N = a.N, P = a.P;
     const float *smp = a.scans + (long long)b * T * N;
     const double phi0 = a.tab[0], dphi = a.tab[1] - a.tab[0], rdphi = 1.0 / dphi;
     const int s_area = (a.area_mode && a.s_area) ? a.s_area[b] : 0;
     const int PA = s_area * P;
 
-    if (LDSROWS) {
-        for (int e = threadIdx.x; e < T * N; e += kThreads) {
-            const int i = e % N;
-            const float v = smp[e];
-            const float nx = (i + 1 < N) ? smp[e + 1] : v;   // hi index clamps to N-1
-            s_rows[e] = make_float2(v, nx - v);
+    // Row loads are issued first and parked in registers; their latency is covered
+    // by the arctangents of phase A, and they are written to LDS just before the
+    // barrier.  (float2 loads: a sample starts on an 8-byte boundary when T*N is even.)
+    constexpr int kMaxStage = 10;
+    const int nvec = (T * N) >> 1;
+    const bool vec_stage = LDSROWS && ((T * N) & 1) == 0 && nvec <= kMaxStage * kThreads &&
+                           ((reinterpret_cast<uintptr_t>(a.scans) & 7) == 0);
+    float2 stage[kMaxStage];
+    if (vec_stage) {
+#pragma unroll
+        for (int v = 0; v < kMaxStage; ++v) {
+            const int e = threadIdx.x + v * kThreads;
+            stage[v] = (e < nvec) ? reinterpret_cast<const float2 *>(smp)[e] : make_float2(0.f, 0.f);
         }
     }
     // ---- phase A: window table ------------------------------------------------
@@ -168,6 +187,8 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         wt.lo_clip[p] = (double)(d - a.depth_f32);
         wt.hi_clip[p] = (double)(d + a.depth_f32);
         wt.dd[p] = (double)d;
+        wt.out_off[p] = a.fixed ? p * P : jj * T * P;   // (jj*T + t)*P, t = 0 when !fixed
+        wt.row_off[p] = a.fixed ? t * N : 0;
         int isarea = 0;
         double step_a = 0.0;
         if (s_area > 0) {
@@ -179,71 +200,118 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         wt.isarea[p] = isarea;
         wt.step_a[p] = step_a;
     }
+    if (LDSROWS) {
+        if (vec_stage) {
+#pragma unroll
+            for (int v = 0; v < kMaxStage; ++v) {
+                const int e = threadIdx.x + v * kThreads;
+                if (e < nvec) reinterpret_cast<float2 *>(s_rows)[e] = stage[v];
+            }
+        } else {
+            for (int e = threadIdx.x; e < T * N; e += kThreads) s_rows[e] = smp[e];
+        }
+    }
     __syncthreads();
 
-    // ---- phase B: one wave per window (or 64/P windows per wave) -----------------
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int sub_per_wave = (P <= 32) ? 64 / P : 1;      // windows handled side by side
-    const int sub = (P <= 32) ? lane / P : 0;
-    const bool sub_ok = sub < sub_per_wave;
+    // ---- phase B ----------------------------------------------------------------
+    constexpr int KV = (P4 >= 0) ? 4 : 1;
+    const int per_win = (P4 > 0) ? P4 : (P4 == 0 ? P / 4 : P);
+    const int total = nwin * per_win;
     const double nm1 = (double)(N - 1);
     float *out_tile = a.out + ((long long)b * a.Ns + j0) * T * P;
     const int tcount = a.fixed ? 1 : T;
 
-    for (int kbase = 0; kbase < P; kbase += 64) {
-        const int k = (P <= 32) ? lane - sub * P : kbase + lane;
-        const bool k_ok = sub_ok && k < P;
-        const double kd = (double)k;
-        for (int p0 = wave * sub_per_wave; p0 < nwin; p0 += kWaves * sub_per_wave) {
-            const int p = p0 + sub;
-            if (!(k_ok && p < nwin)) continue;
-            const double a0 = wt.a0[p], step = wt.step[p];
-            const double lo_clip = wt.lo_clip[p], hi_clip = wt.hi_clip[p], dd = wt.dd[p];
-            const bool isarea = wt.isarea[p] != 0;
-            const double idx = frac_index(a0, step, kd, phi0, dphi, rdphi);
+    for (int g = threadIdx.x; g < total; g += kThreads) {
+        const int p = (P4 > 0) ? g / P4 : g / per_win;
+        const int k0 = (g - p * per_win) * KV;
+        const double a0 = wt.a0[p], step = wt.step[p];
+        const double lo_clip = wt.lo_clip[p], hi_clip = wt.hi_clip[p], dd = wt.dd[p];
+        const bool isarea = wt.isarea[p] != 0;
+        const int out_off = wt.out_off[p], row_off = wt.row_off[p];
+        const double kd0 = (double)k0;
+        double idx[KV], ratio[KV];
+        int lo[KV];
+        bool outb[KV];
+#pragma unroll
+        for (int u = 0; u < KV; ++u) {
+            idx[u] = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
             // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
-            const bool outb = (__double2hiint(idx) < 0) || (idx > nm1);
-            // in range: trunc == floor and idx - floor(idx) is exact; out of range the
-            // value is overwritten by the padding, only the LDS address must stay legal
-            const int lo = min(max((int)idx, 0), N - 1);
-            const double ratio = idx - floor(idx);
-            const int jj = a.fixed ? p / T : p;
-            const int tfirst = a.fixed ? p - jj * T : 0;
-            if (a.dbg_lo) {
-                for (int tt = 0; tt < tcount; ++tt)
-                    a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo;
-            }
-            for (int tt = 0; tt < tcount; ++tt) {
-                const int t = tfirst + tt;
-                float2 vd;
-                if (LDSROWS) {
-                    vd = s_rows[t * N + lo];
-                } else {
-                    const float v = smp[t * N + lo];
-                    vd = make_float2(v, smp[t * N + min(lo + 1, N - 1)] - v);
-                }
-                double ct = (double)vd.x + ratio * (double)vd.y;
+            outb[u] = (__double2hiint(idx[u]) < 0) || (idx[u] > nm1);
+            // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
+            // range the value is replaced by the padding, only the address must stay legal
+            lo[u] = min(max((int)idx[u], 0), N - 1);
+            ratio[u] = __builtin_amdgcn_fract(idx[u]);
+        }
+        if (DBG) {
+            const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
+            for (int tt = 0; tt < tcount; ++tt)
+#pragma unroll
+                for (int u = 0; u < KV; ++u)
+                    a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
+        }
+        for (int tt = 0; tt < tcount; ++tt) {
+            const int roff = row_off + tt * N;
+            float res[KV];
+#pragma unroll
+            for (int u = 0; u < KV; ++u) {
+                const int hi = min(lo[u] + 1, N - 1);
+                const float vlo = LDSROWS ? s_rows[roff + lo[u]] : smp[roff + lo[u]];
+                const float vhi = LDSROWS ? s_rows[roff + hi] : smp[roff + hi];
+                double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
                 if (isarea) {
                     // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
                     const double step_a = wt.step_a[p];
                     float acc = 0.0f;
                     for (int s = 0; s < s_area; ++s) {
-                        double ia = frac_index(a0, step_a, (double)(k * s_area + s), phi0, dphi, rdphi);
-                        ia = rint(fmin(fmax(ia, 0.0), nm1));
-                        const float v = LDSROWS ? s_rows[t * N + (int)ia].x : smp[t * N + (int)ia];
+                        double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
+                        ia = ia < 0.0 ? 0.0 : ia;
+                        ia = ia > nm1 ? nm1 : ia;
+                        const int ii = (int)rint(ia);
+                        const float v = LDSROWS ? s_rows[roff + ii] : smp[roff + ii];
                         acc = (s == 0) ? v : acc + v;
                     }
                     ct = (double)__fdiv_rn(acc, (float)s_area);
                 }
-                if (outb) ct = a.padding;
-                ct = fmin(fmax(ct, lo_clip), hi_clip);
-                if (a.centered) {
+                if (outb[u]) ct = a.padding;
+                // np.clip as compare + select (no NaN canonicalisation needed here)
+                ct = ct < lo_clip ? lo_clip : ct;
+                ct = ct > hi_clip ? hi_clip : ct;
+                if (FAST) {
+                    ct = (ct - dd) * a.rdepth;
+                } else if (a.centered) {
                     ct = ct - dd;
                     ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
                 }
-                out_tile[((long long)jj * T + t) * P + k] = (float)ct;
+                res[u] = (float)ct;
             }
+            float *dst = out_tile + out_off + tt * P + k0;
+            if (KV == 4) *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1 % KV], res[2 % KV], res[3 % KV]);
+            else dst[0] = res[0];
         }
+    }
+}
+
+template <bool LDSROWS, bool FAST, bool DBG>
+void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
+{
+    if (!vec4) cutout_kernel<LDSROWS, -1, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 56) cutout_kernel<LDSROWS, 14, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 48) cutout_kernel<LDSROWS, 12, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 32) cutout_kernel<LDSROWS, 8, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else cutout_kernel<LDSROWS, 0, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+}
+
+template <bool LDSROWS>
+void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
+{
+    const bool fast = a.centered && a.depth_pow2;
+    if (a.dbg_lo) {
+        // test-only variant, no need to specialise further
+        launch_cutout2<LDSROWS, false, true>(a, grid, lds, s, vec4);
+    } else if (fast) {
+        launch_cutout2<LDSROWS, true, false>(a, grid, lds, s, vec4);
+    } else {
+        launch_cutout2<LDSROWS, false, false>(a, grid, lds, s, vec4);
     }
 }
 
@@ -280,13 +348,17 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
         cutout_area_kernel<<<B, kThreads, 0, s>>>(a);
         POF_CHECK_LAUNCH();
     }
-    const size_t row_bytes = (size_t)T * N * sizeof(float2);
-    const size_t tbl = win_table_bytes(fixed ? kTileI * T : kTileI);
+    const size_t row_bytes = (size_t)T * N * sizeof(float);
+    // one window per lane in phase A: tile*T ~ 256 windows when `fixed`, 256 points otherwise
+    a.tile = fixed ? (kMaxWin / T > 0 ? kMaxWin / T : 1) : kMaxWin;
+    if (a.tile > a.Ns) a.tile = a.Ns;
+    const size_t tbl = win_table_bytes(fixed ? a.tile * T : a.tile);
     const bool rows_in_lds = tbl + row_bytes <= 64 * 1024;
     const size_t lds = tbl + (rows_in_lds ? row_bytes : 0);
-    dim3 grid((a.Ns + kTileI - 1) / kTileI, B);
-    if (rows_in_lds) cutout_kernel<true><<<grid, kThreads, lds, s>>>(a);
-    else cutout_kernel<false><<<grid, kThreads, lds, s>>>(a);
+    dim3 grid((a.Ns + a.tile - 1) / a.tile, B);
+    const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    if (rows_in_lds) launch_cutout<true>(a, grid, lds, s, vec4);
+    else launch_cutout<false>(a, grid, lds, s, vec4);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

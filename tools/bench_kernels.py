@@ -1,0 +1,56 @@
+"""Per-kernel timing on the GPU box (events on torch's current stream, which is the
+stream the C-ABI launches on).  Usage: python tools/bench_kernels.py [cutout] [attn] [corr] ..."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from planar_optical_flow_amd import ops, synth
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+which = set(sys.argv[1:]) or {"cutout", "attn", "corr"}
+dev = "cuda"
+if "cutout" in which:
+    tab = ops.phi_table()
+    for (B, T, fixed, P) in [(2048, 5, True, 56), (1024, 11, False, 56), (2048, 5, True, 48)]:
+        sb = synth.make_batch(seed=3, B=B, T=T)
+        scans = torch.from_numpy(sb.scans).to(dev)
+        out = torch.empty((B, 450, T, P), dtype=torch.float32, device=dev)
+        kw = dict(fixed=fixed, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=P, padding_val=29.99, area_mode=True)
+        ms = timeit(lambda: ops.cutout(scans, tab, out=out, **kw))
+        byt = B * (T * 450 * 4 + 450 * T * P * 4)
+        print("cutout B=%d T=%d fixed=%d P=%d: %.3f ms  %.0f GB/s  %.2f Msamples/s" % (B, T, fixed, P, ms, byt / ms / 1e6, B / ms / 1e3))
+    # dense 3600-pt geometry (rows do not fit LDS)
+    tab2 = ops.phi_table(np.radians(0.1), 3600)
+    sb = synth.make_batch(seed=5, B=64, T=11, N=3600, angle_inc=np.radians(0.1))
+    scans = torch.from_numpy(sb.scans).to(dev)
+    out = torch.empty((64, 3600, 11, 56), dtype=torch.float32, device=dev)
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56, padding_val=29.99, area_mode=True)
+    ms = timeit(lambda: ops.cutout(scans, tab2, out=out, **kw), iters=5)
+    byt = 64 * (11 * 3600 * 4 + 3600 * 11 * 56 * 4)
+    print("cutout dense3600 B=64 T=11: %.3f ms  %.0f GB/s" % (ms, byt / ms / 1e6))
+if "attn" in which:
+    for B in (16, 64, 256):
+        N, E, F = 450, 128, 3584
+        g = torch.Generator(device=dev).manual_seed(10)
+        ex = torch.randn((B, N, E), device=dev, generator=g) * 0.3
+        et = torch.randn((B, N, E), device=dev, generator=g) * 0.3
+        x = torch.randn((B, N, F), device=dev, generator=g)
+        t = torch.randn((B, N, F), device=dev, generator=g)
+        out = torch.empty_like(x)
+        ms = timeit(lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), iters=10)
+        per = 3 * N * F * 4 + 2 * N * E * 4 + 2 * N * 11 * 4
+        print("attn B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
+if "corr" in which:
+    for (B, C, n) in [(4096, 256, 57), (256, 256, 450)]:
+        f1 = torch.randn((B, C, n), device=dev); f2 = torch.randn((B, C, n), device=dev)
+        out = torch.empty((B, 11, n), device=dev)
+        ms = timeit(lambda: ops.band_correlation(f1, f2, 3, 5, out=out), iters=10)
+        byt = B * (2 * C * n * 4 + 11 * n * 4)
+        print("corr B=%d C=%d n=%d: %.3f ms  %.0f GB/s  %.1f TFLOP/s" % (B, C, n, ms, byt / ms / 1e6, B * 2 * 11 * n * 3 * C / ms / 1e9))
