@@ -91,6 +91,23 @@ int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int
                         void *workspace, size_t workspace_bytes, pof_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * A3 on caller-supplied scanner-frame points (the reference's own signature):
+ *   get_displacement_from_odometry(scan1_xy, odom0, odom1)   src/utils/utils.py:639-662
+ *   get_velocity_from_odometry(scan1_xy, odom0, odom1)       src/utils/utils.py:609-636
+ * xy, flow [B][N][2] float64; odom [B][3]; tab only needed when canonical != 0.
+ * ---------------------------------------------------------------------- */
+int pof_flow_from_xy(const double *xy, const double *odom0, const double *odom1, int flow_kind,
+                     int canonical, const double *tab, double *flow, int B, int N,
+                     pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * A2 inverse  xy_to_rphi(x, y) -> (hypot, atan2(y, x))   src/utils/utils.py:39-43
+ * float64, n elements.
+ * ---------------------------------------------------------------------- */
+int pof_xy_to_rphi(const double *x, const double *y, double *r, double *phi, long long n,
+                   pof_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * A4 stand-alone frame rotation of a flow field
  *   global_to_canonical_flow / canonical_to_global_flow(_torch)
  *                                             src/utils/utils.py:62-105

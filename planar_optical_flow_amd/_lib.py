@@ -27,6 +27,8 @@ SIGNATURES = {
     "pof_scan_preprocess_workspace_bytes": (_sz, [_i, _i]),
     "pof_scan_preprocess": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                                  _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pof_flow_from_xy": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
+    "pof_xy_to_rphi": (_i, [_p, _p, _p, _p, _ll, _p]),
     "pof_rotate_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
     "pof_det_to_canonical": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "pof_canonical_to_det": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),

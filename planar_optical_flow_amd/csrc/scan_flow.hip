@@ -533,7 +533,84 @@ __global__ void canonical_to_det_kernel(const float *ranges, const double *tab, 
     det_r[p] = ty / cos(tphi);
 }
 
+// ---- A3 on caller-supplied cartesian points ------------------------------------
+// get_displacement_from_odometry / get_velocity_from_odometry take scanner-frame
+// xy, not ranges (src/utils/utils.py:609-662): convenience path, one workgroup
+// per sample, motion evaluated in the prologue.
+__global__ __launch_bounds__(256) void flow_from_xy_kernel(const double *xy, const double *odom0,
+                                                           const double *odom1, int kind, int canonical,
+                                                           const double *tab, double *out, int N)
+{
+    __shared__ double s_sc[4];
+    __shared__ double s_mot[8];
+    const int b = blockIdx.x;
+    const double *o0 = odom0 + 3 * b, *o1 = odom1 + 3 * b;
+    if (threadIdx.x < 2) {
+        const int which = threadIdx.x;
+        const double ang = which ? ((kind == 1) ? o1[2] - o0[2] : o1[2]) : o0[2];
+        sincos(ang, &s_sc[2 * which], &s_sc[2 * which + 1]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) motion_params(kind, o0, o1, s_sc[0], s_sc[1], s_sc[2], s_sc[3], s_mot);
+    __syncthreads();
+    for (int i = threadIdx.x; i < N; i += blockDim.x) {
+        const long long p = (long long)b * N + i;
+        const double px = xy[2 * p], py = xy[2 * p + 1];
+        double fx, fy;
+        if (kind == 0) {
+            fx = fma(py, s_mot[1], px * s_mot[0]) - s_mot[4];
+            fy = fma(py, s_mot[3], px * s_mot[2]) - s_mot[5];
+        } else if (kind == 1) {
+            fx = (fma(py, s_mot[1], px * s_mot[0]) - s_mot[4]) - px;
+            fy = (fma(py, s_mot[3], px * s_mot[2]) - s_mot[5]) - py;
+        } else {
+            fx = -s_mot[4] - (py * -s_mot[6]);
+            fy = -s_mot[5] - (px * s_mot[6]);
+        }
+        if (canonical) {
+            const double c = tab[N + 2 * i], sn = tab[N + 2 * i + 1];
+            const double gx = c * fx + (-sn) * fy, gy = sn * fx + c * fy;
+            fx = gx;
+            fy = gy;
+        }
+        out[2 * p] = fx;
+        out[2 * p + 1] = fy;
+    }
+}
+
+// ---- A2 inverse: xy_to_rphi (src/utils/utils.py:39-43) -------------------------
+__global__ void xy_to_rphi_kernel(const double *x, const double *y, double *r, double *phi, long long n)
+{
+    long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    r[p] = hypot(x[p], y[p]);
+    phi[p] = atan2(y[p], x[p]);
+}
+
 }  // namespace
+
+extern "C" int pof_flow_from_xy(const double *xy, const double *odom0, const double *odom1, int flow_kind,
+                                int canonical, const double *tab, double *flow, int B, int N,
+                                pof_stream_t stream)
+{
+    if (!xy || !odom0 || !odom1 || !flow || B < 0 || N < 1) return POF_E_BADARG;
+    if (flow_kind < 0 || flow_kind > 2) return POF_E_BADARG;
+    if (canonical && !tab) return POF_E_BADARG;
+    if (B == 0) return POF_OK;
+    flow_from_xy_kernel<<<B, 256, 0, pof_stream(stream)>>>(xy, odom0, odom1, flow_kind, canonical, tab, flow, N);
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
+extern "C" int pof_xy_to_rphi(const double *x, const double *y, double *r, double *phi, long long n,
+                              pof_stream_t stream)
+{
+    if (!x || !y || !r || !phi || n < 0) return POF_E_BADARG;
+    if (n == 0) return POF_OK;
+    xy_to_rphi_kernel<<<(unsigned)((n + 255) / 256), 256, 0, pof_stream(stream)>>>(x, y, r, phi, n);
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
 
 extern "C" int pof_laser_phi(double angle_inc, int num_pts, double *tab, pof_stream_t stream)
 {

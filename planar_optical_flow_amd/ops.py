@@ -183,6 +183,34 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
     return out
 
 
+def flow_from_xy(xy, odom0, odom1, flow_kind=FLOW_DISPLACEMENT, canonical=False, tab=None):
+    """A3 on scanner-frame points: xy [B,N,2] float64, odom [B,3] float64 -> flow [B,N,2] float64."""
+    xy = _dev(xy, torch.float64, "xy")
+    odom0 = _dev(odom0, torch.float64, "odom0")
+    odom1 = _dev(odom1, torch.float64, "odom1")
+    if xy.dim() != 3 or xy.shape[-1] != 2 or tuple(odom0.shape) != (xy.shape[0], 3) or odom0.shape != odom1.shape:
+        raise ValueError("xy must be [B,N,2] and odometry [B,3]")
+    if canonical and (tab is None or tab.numel() != 3 * xy.shape[1]):
+        raise ValueError("canonical output needs the angle table of this N")
+    out = torch.empty_like(xy)
+    with torch.cuda.device(xy.device):
+        _lib.call("pof_flow_from_xy", _ptr(xy), _ptr(odom0), _ptr(odom1), int(flow_kind), int(bool(canonical)),
+                  _ptr(tab), _ptr(out), xy.shape[0], xy.shape[1], _stream())
+    return out
+
+
+def xy_to_rphi(x, y):
+    """A2 inverse on float64 device tensors of equal shape."""
+    x = _dev(x, torch.float64, "x")
+    y = _dev(y, torch.float64, "y")
+    if x.shape != y.shape:
+        raise ValueError("x and y must have the same shape")
+    r, phi = torch.empty_like(x), torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        _lib.call("pof_xy_to_rphi", _ptr(x), _ptr(y), _ptr(r), _ptr(phi), x.numel(), _stream())
+    return r, phi
+
+
 def rotate_flow(flow, tab, to_canonical=True, out=None):
     """A4 on a [B,N,2] (or [N,2]) float32/float64 device tensor."""
     if flow.dtype not in (torch.float32, torch.float64):

@@ -1,0 +1,88 @@
+"""Box-regression head of the reference (src/model/box_regression.py).
+
+PointNet trunk (1x1 convs 3->64->64->128->1024 + BN + LeakyReLU(0.1), max over
+points) and an FC head 1024->512->256->target_dim.  These are dense GEMMs and
+stay on rocBLAS / MIOpen through PyTorch-ROCm; what
+this module must preserve is the checkpoint ABI: the 72 state-dict keys,
+including the unused top-level ``conv1..conv4`` the reference creates by
+subclassing its PointNet, and the construction order (so that a given seed
+yields the reference's initial weights).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .box_regression_fn import _model_eval_fn, _model_fn
+
+
+def _pointwise(cin, cout):
+    return nn.Sequential(nn.Conv1d(cin, cout, kernel_size=1, padding=0), nn.BatchNorm1d(cout),
+                         nn.LeakyReLU(negative_slope=0.1, inplace=True))
+
+
+def _dense(cin, cout, batch_norm=True, nonlinearity=True):
+    layers = [nn.Linear(cin, cout)]
+    if batch_norm:
+        layers.append(nn.BatchNorm1d(cout))
+    if nonlinearity:
+        layers.append(nn.LeakyReLU(negative_slope=0.1, inplace=True))
+    return layers[0] if len(layers) == 1 else nn.Sequential(*layers)
+
+
+def regression_loss2(pred, target, alpha=0.5):
+    """:52-67.  L1 on the box dimensions + alpha * L1 on the orientation residual
+    (+ L1 on z for the 5-target 3-D variant)."""
+    ori = torch.mean(torch.abs(pred[..., -1] - target[..., -1]))
+    if pred.shape[1] == 5:
+        z = torch.mean(torch.abs(pred[..., 0] - target[..., 0]))
+        dims = torch.mean(torch.sum(torch.abs(pred[:, 1:-1] - target[:, 1:-1]), dim=1))
+        return z + dims + alpha * ori
+    if pred.shape[1] == 3:
+        dims = torch.mean(torch.sum(torch.abs(pred[:, :-1] - target[:, :-1]), dim=1))
+        return dims + alpha * ori
+    return None
+
+
+class PointNet(nn.Module):
+    def __init__(self, input_dim=3):
+        super().__init__()
+        self.conv1 = _pointwise(input_dim, 64)
+        self.conv2 = _pointwise(64, 64)
+        self.conv3 = _pointwise(64, 128)
+        self.conv4 = _pointwise(128, 1024)
+
+    def forward(self, x):  # x [B, C, n]
+        x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
+        return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
+
+
+class BoundingBoxRegressor(PointNet):
+    def __init__(self, cfg):
+        super().__init__()  # creates the (unused) top-level conv1..conv4 of the checkpoint ABI
+        self.dropout = cfg["dropout"]
+        self.backbone = PointNet(input_dim=cfg["input_dim"])
+        self.fc1 = _dense(1024, 512)
+        self.fc2 = _dense(512, 256)
+        self.fc3 = _dense(256, cfg["target_dim"], batch_norm=False, nonlinearity=False)
+        self.loss_fn = regression_loss2
+        for m in self.modules():
+            if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+                nn.init.kaiming_normal_(m.weight, a=0.1, nonlinearity="leaky_relu")
+            elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    @staticmethod
+    def model_fn(model, batch_data):
+        return _model_fn(model, batch_data)
+
+    @staticmethod
+    def model_eval_fn(model, batch_data):
+        return _model_eval_fn(model, batch_data)
+
+    def forward(self, x):  # x [B, n, C]
+        x = self.backbone(x.permute(0, 2, 1))
+        x = self.fc2(self.fc1(x))
+        if self.dropout > 0.0:
+            x = F.dropout(x, p=self.dropout, training=self.training)
+        return self.fc3(x)

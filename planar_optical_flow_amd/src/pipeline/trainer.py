@@ -1,0 +1,100 @@
+"""Train / eval loop (reference src/pipeline/trainer.py) with the multi-GPU
+gradient exchange added: between ``loss.backward()`` and gradient clipping the
+gradients are averaged over all ranks through one flat RCCL all-reduce
+(planar_optical_flow_amd.dist.GradientAllReduce), so clipping and Adam see the
+global-batch gradient exactly as on one GPU."""
+import signal
+
+import torch
+from torch.nn.utils import clip_grad_norm_
+
+from planar_optical_flow_amd import dist as pdist
+
+
+class Trainer:
+    def __init__(self, logger, optimizer, cfg):
+        self._logger, self._optim = logger, optimizer
+        self._epoch, self._step = 0, 0
+        self._grad_norm_clip = cfg["grad_norm_clip"]
+        self._ckpt_interval = cfg["ckpt_interval"]
+        self._eval_interval = cfg["eval_interval"]
+        self._max_epoch = cfg["epoch"]
+        self._stop = False
+        self._reducer = None
+        try:
+            signal.signal(signal.SIGINT, self._on_signal)
+            signal.signal(signal.SIGTERM, self._on_signal)
+        except ValueError:  # not the main thread (e.g. under a test runner)
+            pass
+
+    def _on_signal(self, signum, frame):
+        self._stop = True
+        self._logger.log_info("Received signal %s." % signum)
+
+    # ---- evaluation ---------------------------------------------------------------
+    def evaluate(self, model, eval_loader, tb_prefix):
+        model.eval()
+        keys = ("iou", "loss_z", "loss_dim", "loss_ori")
+        acc = dict.fromkeys(keys, 0.0)
+        total = 0.0
+        for batch in eval_loader:
+            if self._stop:
+                return 1
+            with torch.no_grad():
+                loss, _, rtn = model.model_eval_fn(model, batch)
+            total += loss.item()
+            for k in keys:
+                acc[k] += rtn[k]
+        n = max(len(eval_loader), 1)
+        stats = {"eval_loss": total / n, "avg_iou": acc["iou"] / n, "avg_loss_z": acc["loss_z"] / n,
+                 "avg_loss_dim": acc["loss_dim"] / n, "avg_loss_ori": acc["loss_ori"] / n}
+        for k, v in stats.items():
+            self._logger.add_scalar("%s_%s" % (tb_prefix, k), v, self._step)
+            self._logger.log_info("%s: %s" % (k, v))
+        return 0
+
+    # ---- training -------------------------------------------------------------------
+    def train(self, model, train_loader, eval_loader=None):
+        for self._epoch in range(0, self._max_epoch):
+            if self._stop:
+                self._logger.save_sigterm_ckpt(model, self._optim, self._epoch, self._step)
+                return 1
+            self._train_epoch(model, train_loader)
+            if not self._stop:
+                if self._epoch % self._ckpt_interval == 0 or self._epoch == self._max_epoch:
+                    self._logger.save_ckpt("ckpt_e%d.pth" % self._epoch, model, self._optim, self._epoch,
+                                           self._step)
+                if eval_loader is not None and (self._epoch % self._eval_interval == 0
+                                                or self._epoch == self._max_epoch):
+                    self.evaluate(model, eval_loader, tb_prefix="VAL")
+            self._logger.flush()
+        return 0
+
+    def _train_batch(self, model, batch, ratio):
+        model.train()
+        self._optim.zero_grad()
+        self._optim.set_lr(self._epoch + ratio)
+        loss, tb_dict, _ = model.model_fn(model, batch)
+        loss.backward()
+        if pdist.is_distributed():
+            if self._reducer is None:
+                self._reducer = pdist.GradientAllReduce(model)
+            self._reducer()
+        if self._grad_norm_clip > 0:
+            clip_grad_norm_(model.parameters(), self._grad_norm_clip)
+        self._optim.step()
+        self._logger.add_scalar("TRAIN_lr", self._optim.get_lr(), self._step)
+        self._logger.add_scalar("TRAIN_loss", loss.item(), self._step)
+        self._logger.add_scalar("TRAIN_epoch", self._epoch + ratio, self._step)
+        for k, v in tb_dict.items():
+            self._logger.add_scalar("TRAIN_%s" % k, v, self._step)
+        return loss.item()
+
+    def _train_epoch(self, model, train_loader):
+        total, n = 0.0, max(len(train_loader), 1)
+        for ib, batch in enumerate(train_loader):
+            if self._stop:
+                return
+            total += self._train_batch(model, batch, ratio=ib / n)
+            self._step += 1
+        self._logger.log_info("Current epoch: %d, training loss: %s" % (self._epoch, total / n))

@@ -1,0 +1,185 @@
+"""The reference's own call sites, spelled the reference's way (``import
+src.utils.utils as u``), running on the HIP path: NumPy in -> NumPy out."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_numpy as R
+from planar_optical_flow_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+
+@pytest.fixture(scope="module")
+def u():
+    import src.utils.utils as _u
+    return _u
+
+
+@pytest.fixture(scope="module")
+def geo(golden):
+    g = golden("scan_geometry")
+    return g, synth.make_batch(seed=int(g["seed"]), B=int(g["B"]), T=2, mixed_classes=True)
+
+
+def test_getitem_sequence_like_the_reference(u, geo):
+    """dataset_dr_spaam.py:384-409, one sample at a time."""
+    g, sb = geo
+    scan_phi = u.get_laser_phi()
+    assert np.array_equal(scan_phi, R.laser_phi())
+    for b in range(3):
+        cur = sb.scans[b, -1]
+        d = sb.dets[b]
+        wc, wa, wp = [list(map(tuple, d[k])) for k in ("wc", "wa", "wp")]
+        target_cls, target_reg = u.get_regression_target(cur, scan_phi, wc, wa, wp)
+        assert target_cls.dtype == np.int64 and target_reg.dtype == np.float32
+        assert np.array_equal(target_cls, g["target_cls"][b])
+        np.testing.assert_allclose(target_reg, g["target_reg"][b], atol=1e-6)
+        cur_scan_xy = np.array(u.rphi_to_xy(cur, scan_phi)).T
+        np.testing.assert_allclose(cur_scan_xy, g["xy"][b], atol=1e-14)
+        flow = u.get_displacement_from_odometry(cur_scan_xy, sb.odom0[b], sb.odom1[b])
+        np.testing.assert_allclose(flow, g["disp"][b], atol=1e-12)
+        flow_c = u.global_to_canonical_flow(flow, scan_phi)
+        np.testing.assert_allclose(flow_c, g["disp_canonical"][b], atol=1e-12)
+        np.testing.assert_allclose(u.canonical_to_global_flow(flow_c, scan_phi), g["disp_back"][b], atol=1e-12)
+        np.testing.assert_allclose(u.get_flow_target(cur, scan_phi, sb.odom0[b], sb.odom1[b], True),
+                                   g["flow_target_canonical"][b], atol=1e-12)
+        np.testing.assert_allclose(u.get_velocity_from_odometry(cur_scan_xy, sb.odom0[b], sb.odom1[b]),
+                                   g["velocity"][b], atol=1e-12)
+        dets = wc + wa + wp
+        radii = [0.6] * len(wc) + [0.4] * len(wa) + [0.35] * len(wp)
+        assert np.array_equal(u.closest_detection(cur, scan_phi, dets, radii), g["closest"][b])
+    assert np.array_equal(u.closest_detection(sb.scans[0, -1], scan_phi, [], []), np.zeros(450, dtype=int))
+    with pytest.raises(AssertionError):
+        u.closest_detection(sb.scans[0, -1], scan_phi, [(1.0, 0.0)], [])
+
+
+def test_a5_and_polar_helpers(u, geo):
+    g, sb = geo
+    phi = u.get_laser_phi()
+    r, p = u.canonical_to_global(sb.scans[0, -1], phi, g["a5_dx"], g["a5_dy"])
+    np.testing.assert_allclose(r, g["a5_det_r"], rtol=1e-14)
+    x, y = u.global_to_canonical(sb.scans[0, -1], phi, r, p)
+    np.testing.assert_allclose(x, g["a5_back_x"], atol=1e-13)
+    rr, pp = u.xy_to_rphi(g["xy"][0][:, 0], g["xy"][0][:, 1])
+    np.testing.assert_allclose(rr, sb.scans[0, -1].astype(np.float64), rtol=1e-15)
+    np.testing.assert_allclose(pp, phi, atol=1e-15)
+
+
+def test_cutout_and_nms_dropin(u, golden):
+    from cases import CUTOUT_CASES
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES["dr_spaam"]
+    phi = u.get_laser_phi(np.radians(inc), n)
+    got = u.scans_to_cutout(g["dr_spaam_scans"][0], phi, **kw)
+    assert got.dtype == np.float32 and got.shape == g["dr_spaam_out"][0].shape
+    assert np.array_equal(got, R.cutout(g["dr_spaam_scans"][0], phi, atan_mode="cr", **kw))
+    gn = golden("nms")
+    xy, cls, inst = u.nms_predicted_center(gn["scan0"], u.get_laser_phi(), gn["cls0"], gn["reg0"], 0.5)
+    assert np.array_equal(inst, gn["inst0"]) and inst.dtype == np.int32
+    np.testing.assert_allclose(xy, gn["xy0"], atol=1e-12)
+    assert np.array_equal(cls, gn["keepcls0"])
+    with pytest.raises(AssertionError):
+        u.nms_predicted_center(gn["scan0"], u.get_laser_phi(), gn["cls0"][:, 0], gn["reg0"])
+
+
+def test_batch_preprocessor_matches_per_sample_oracle():
+    """DROWDataset2.__getitem__ + collate_batch for a whole batch in three launches."""
+    from planar_optical_flow_amd.preprocess import DROWBatchPreprocessor
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+              padding_val=29.99, area_mode=True)
+    pre = DROWBatchPreprocessor(cutout_kwargs=kw)
+    sb = synth.make_batch(seed=21, B=16, T=6)
+    dets = pre.make_detections([d["wc"] for d in sb.dets], [d["wa"] for d in sb.dets], [d["wp"] for d in sb.dets])
+    batch = pre(torch.from_numpy(sb.scans).cuda(), torch.from_numpy(sb.odom0).cuda(),
+                torch.from_numpy(sb.odom1).cuda(), dets)
+    assert batch["input"].shape == (16, 450, 6, 56) and batch["target_flow"].shape == (16, 450, 2)
+    phi = R.laser_phi()
+    for b in (0, 7, 15):
+        cur = sb.scans[b, -1]
+        d = sb.dets[b]
+        cls, reg = R.regression_target(cur, phi, d["wc"], d["wa"], d["wp"])
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        flow = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
+        mask = R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]) * R.valid_point_mask(cur)
+        assert np.array_equal(batch["target_cls"][b].cpu().numpy(), cls)
+        np.testing.assert_allclose(batch["target_reg"][b].cpu().numpy(), reg, atol=1e-6)
+        np.testing.assert_allclose(batch["target_flow"][b].cpu().numpy(), flow, atol=5e-6)   # float32 output
+        assert np.array_equal(batch["exclude_mask"][b].cpu().numpy().astype(np.float64), mask)
+        assert np.array_equal(batch["input"][b].cpu().numpy(), R.cutout(sb.scans[b], phi, atan_mode="cr", **kw))
+
+
+def test_rotate_iou_and_eval_metrics_dropin(golden):
+    from src.utils.rotate_iou import rotate_iou_batched, rotate_iou_gpu_eval
+    from src.utils.eval_utils import flow_epe, loss_fn_eval
+    b1 = np.array([[0, 0, 0.7, 1, 1, 1, 0]])
+    b2 = np.array([[0, 0, 0, 1, 1, 1, 0]])
+    np.testing.assert_allclose(rotate_iou_gpu_eval(b1, b2, is_3d=True)[0, 0], 0.3 / 1.7, rtol=1e-6)  # reference __main__
+    assert rotate_iou_gpu_eval(np.zeros((0, 5)), np.zeros((3, 5))).shape == (0, 3)
+    rng = np.random.default_rng(4)
+    boxes = np.concatenate([rng.uniform(-1, 1, (5, 2)), rng.uniform(0.4, 1.2, (5, 2)), rng.uniform(-3, 3, (5, 1))], 1)
+    qs = [np.concatenate([rng.uniform(-1, 1, (k, 2)), rng.uniform(0.4, 1.2, (k, 2)), rng.uniform(-3, 3, (k, 1))], 1)
+          for k in (3, 0, 5, 1, 2)]
+    got = rotate_iou_batched(boxes, qs)
+    for i in range(5):
+        want = R.rotate_iou(boxes[i:i + 1], qs[i])[0] if len(qs[i]) else np.zeros(0)
+        np.testing.assert_allclose(got[i], want, atol=1e-5)
+    g = golden("losses")
+    epe, aae = loss_fn_eval(g["pred"], g["target"])
+    np.testing.assert_allclose(epe.cpu().numpy(), g["epe"], rtol=1e-5)
+    np.testing.assert_allclose(aae.cpu().numpy(), g["aae"], rtol=1e-4)
+    np.testing.assert_allclose(flow_epe(g["pred"], g["target"], g["mask"]), g["masked"], rtol=1e-5)
+
+
+def test_spatial_attention_module_with_reference_weights(golden):
+    """The nn.Module mirror loaded with the reference module's state dict."""
+    from src.depracted.model.dr_spaam import _SpatialAttention
+    from src.depracted.model.prototype import fusion
+    g = golden("spatial_attn")
+    att = _SpatialAttention(n_pts=14, n_channel=32, alpha=0.5, window_size=11)
+    sd = {k[3:].replace("conv_0_", "conv.0.").replace("conv_1_", "conv.1."): torch.from_numpy(g[k])
+          for k in g.files if k.startswith("sd_")}
+    att.load_state_dict(sd)
+    att = att.cuda().eval()
+    with torch.no_grad():
+        out, band = att(torch.from_numpy(g["x"]).cuda(), torch.from_numpy(g["tmpl"]).cuda())
+    np.testing.assert_allclose(band.cpu().numpy(), g["band"], rtol=1e-3, atol=1e-3)   # MIOpen conv vs MKL
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-3, atol=1e-4)
+    gc = golden("band_corr")
+    np.testing.assert_allclose(fusion(torch.from_numpy(gc["f1"]).cuda(), torch.from_numpy(gc["f2"]).cuda()).cpu().numpy(),
+                               gc["out"], rtol=1e-4, atol=1e-3)
+
+
+def test_box_regressor_dropin(golden):
+    """BoxRegressor(ckpt)(points, centre, ori): the segment it feeds the network is
+    the reference's (as a set), the forward equals the module's."""
+    from planar_optical_flow_amd.box_regressor import BoxRegressor
+    from src.model.get_model import get_model
+    torch.manual_seed(61)
+    model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3})
+    br = BoxRegressor({"model_state": model.state_dict()}, gpu=True, seed=5)
+    rng = np.random.default_rng(6)
+    centre = np.array([2.0, 1.0])
+    pts = np.concatenate([centre + rng.normal(0, 0.15, (40, 2)), rng.uniform(-8, 8, (300, 2))])
+    seg = br.generate_segment(pts, centre, 0.4)
+    want = R.radius_query(pts, centre, 0.4)
+    assert np.array_equal(seg, want)
+    out = br(pts, centre, 0.3)
+    assert out.shape == (5,) and np.allclose(out[:2], centre)
+    assert br(pts, np.array([50.0, 50.0]), 0.0) is None            # fewer than 5 points
+    outs = br.regress_batch(pts, [centre, np.array([50.0, 50.0])], [0.3, 0.0])
+    assert outs[1] is None and outs[0].shape == (5,)
+    # max-pool over points makes the prediction independent of the resampling order and
+    # of how often a point is repeated: compare with a direct forward on the unique set
+    x = torch.from_numpy(np.hstack([want - centre, np.full((len(want), 1), 0.3)])).float()[None].cuda()
+    with torch.no_grad():
+        direct = br.model(x)[0].cpu().numpy()
+    np.testing.assert_allclose(out[2:4], direct[:2], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out[4], direct[2] + 0.3, rtol=1e-4, atol=1e-5)

@@ -1,0 +1,112 @@
+"""Host-side mirror of the reference's model / pipeline API (CPU)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+PKG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd")
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)  # makes the reference's `import src....` spelling work
+
+from src.model.box_regression import regression_loss2  # noqa: E402
+from src.model.get_model import get_model  # noqa: E402
+from src.pipeline.optim import _ExpDecayScheduler  # noqa: E402
+from src.pipeline.pipeline import Pipeline  # noqa: E402
+
+CFG2D = {"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}
+CFG3D = {"type": "box_reg", "input_dim": 4, "target_dim": 5, "dropout": 0.3}
+
+
+@pytest.mark.parametrize("tag,cfg", [("2d", CFG2D), ("3d", CFG3D)])
+def test_box_head_matches_reference(golden, tag, cfg):
+    """Same seed -> the reference's initial weights (checkpoint ABI: key names and
+    order, construction order) -> the reference's output."""
+    g = golden("box_head")
+    torch.manual_seed(61)
+    m = get_model(cfg).eval()
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys_" + tag])
+    assert len(sd) == 72
+    np.testing.assert_allclose([float(v.abs().sum()) for v in sd.values()], g["abs_sum_" + tag], rtol=1e-6)
+    with torch.no_grad():
+        y = m(torch.from_numpy(g["in_" + tag]))
+    np.testing.assert_allclose(y.numpy(), g["out_" + tag], rtol=1e-4, atol=1e-5)
+    loss = regression_loss2(y, torch.from_numpy(g["tgt_" + tag]))
+    np.testing.assert_allclose(loss.item(), g["loss_" + tag], rtol=1e-5)
+
+
+def test_get_model_rejects_unknown():
+    with pytest.raises(NotImplementedError):
+        get_model({"type": "nope"})
+
+
+def test_exp_decay_scheduler():
+    s = _ExpDecayScheduler(epoch0=2, lr0=1e-3, epoch1=10, lr1=1e-5)
+    assert s(0) == 1e-3 and s(11) == 1e-5
+    np.testing.assert_allclose(s(6), 1e-4, rtol=1e-12)
+
+
+class _Loader:
+    def __init__(self, n_batches, seed, with_eval=False):
+        rng = np.random.default_rng(seed)
+        self.batches = []
+        for _ in range(n_batches):
+            b = {"input": rng.normal(0, 0.2, (8, 64, 3)), "target": rng.normal(0, 0.2, (8, 3))}
+            self.batches.append(b)
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def _pipe_cfg(tmp_path, epochs=2):
+    return {"Logger": {"log_dir": str(tmp_path), "tag": "t", "log_fname": "log.txt", "backup_list": []},
+            "Optim": {"scheduler_kwargs": {"epoch0": 0, "lr0": 1e-3, "epoch1": 5, "lr1": 1e-4}},
+            "Trainer": {"grad_norm_clip": 1.0, "ckpt_interval": 1, "eval_interval": 100, "epoch": epochs}}
+
+
+def test_pipeline_trains_and_checkpoints(tmp_path):
+    torch.manual_seed(0)
+    model = get_model(CFG2D)
+    pipe = Pipeline(model, _pipe_cfg(tmp_path))
+    loader = _Loader(3, 1)
+    before = [p.detach().clone() for p in model.parameters()]
+    assert pipe.train(model, loader) == 0
+    assert any(not torch.equal(a, b) for a, b in zip(before, model.parameters()))
+    run = [d for d in os.listdir(tmp_path) if d.endswith("_t")][0]
+    ck = os.path.join(tmp_path, run, "ckpt", "ckpt_e1.pth")
+    state = torch.load(ck, weights_only=False)
+    assert set(state) == {"epoch", "step", "model_state", "optimizer_state"} and state["step"] == 6
+    model2 = get_model(CFG2D)
+    pipe2 = Pipeline(model2, _pipe_cfg(tmp_path))
+    assert pipe2.load_ckpt(model2, ck) == (1, 6)
+    for a, b in zip(model.state_dict().values(), model2.state_dict().values()):
+        assert torch.equal(a, b)
+    assert os.path.exists(os.path.join(tmp_path, run, "tb", "scalars.jsonl")) or \
+        os.listdir(os.path.join(tmp_path, run, "tb"))
+    pipe.close()
+    pipe2.close()
+
+
+def test_sigterm_checkpoint(tmp_path):
+    model = get_model(CFG2D)
+    pipe = Pipeline(model, _pipe_cfg(tmp_path, epochs=3))
+    assert not pipe.sigterm_ckpt_exists()
+    pipe.trainer._on_signal(15, None)          # what SIGTERM does
+    assert pipe.train(model, _Loader(2, 2)) == 1
+    assert pipe.sigterm_ckpt_exists()
+    assert pipe.load_sigterm_ckpt(model) == (0, 0)
+    pipe.close()
+
+
+def test_collate_batch_stacks_like_reference():
+    from planar_optical_flow_amd.preprocess import collate_batch
+    samples = [{"scans": np.full((3, 4), i, np.float32), "seq_name": "s%d" % i, "target_cls": np.arange(4)}
+               for i in range(5)]
+    out = collate_batch(samples)
+    assert out["scans"].shape == (5, 3, 4) and out["target_cls"].shape == (5, 4)
+    assert out["seq_name"] == ["s0", "s1", "s2", "s3", "s4"]

@@ -234,6 +234,28 @@ def main():
     np.savez_compressed(os.path.join(OUT, "spatial_attn_w7.npz"), x=x2.numpy(), tmpl=t2.numpy(),
                         out=out2.numpy(), band=band2.numpy(), emb_x=e2x.numpy(), emb_t=e2t.numpy())
 
+    # ---------------- A14: box head forward (weights rebuilt from the seed) ---
+    from src.model.get_model import get_model as ref_get_model
+    from src.model.box_regression import regression_loss2 as ref_loss2
+    gb = {}
+    for tag, cfg_m, npts in (("2d", {"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}, 64),
+                             ("3d", {"type": "box_reg", "input_dim": 4, "target_dim": 5, "dropout": 0.3}, 256)):
+        torch.manual_seed(61)
+        mref = ref_get_model(cfg_m)
+        mref.eval()
+        xin = torch.randn(4, npts, cfg_m["input_dim"])
+        tgt = torch.randn(4, cfg_m["target_dim"])
+        with torch.no_grad():
+            yout = mref(xin)
+            lval = ref_loss2(yout, tgt)
+        gb["in_" + tag] = xin.numpy()
+        gb["tgt_" + tag] = tgt.numpy()
+        gb["out_" + tag] = yout.numpy()
+        gb["loss_" + tag] = lval.numpy()
+        gb["keys_" + tag] = np.array(list(mref.state_dict().keys()))
+        gb["abs_sum_" + tag] = np.array([float(v.abs().sum()) for v in mref.state_dict().values()])
+    np.savez_compressed(os.path.join(OUT, "box_head.npz"), **gb)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
