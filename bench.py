@@ -35,6 +35,26 @@ N_PTS = 450
 BATCH = 4096
 
 
+def pmc_traffic(prefixes):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_pmc_traffic.json,
+    produced by tools/collect_profiles.sh with separate --pmc FETCH_SIZE / WRITE_SIZE runs).
+    Units are KiB; on gfx950 FETCH_SIZE counts 128-B read requests as 64 B (MI355X_MICROARCH.md
+    section HBM), hence the factor 2 on the read side.  Returns (bytes, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        tot = 0.0
+        for k, v in d.items():
+            if k.startswith(prefixes):
+                tot += (2.0 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0
+        return (tot if tot > 0 else None), os.path.relpath(files[-1], REPO)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -208,6 +228,9 @@ def main():
         bytes_per_scan = 4 * N + (8 + 8 + 8 + 4) * N
         launch_ms = dev_ms / a.steps
         achieved = bytes_per_scan * B / (launch_ms * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(("scan_params_kernel", "scan_preprocess_kernel"))
+        if B != BATCH:
+            traffic = None
         result = {
             "metric": "scans/sec, flow-only preprocess of 450-pt synthetic scan pairs, batch 4096 per GPU "
                       "(+ flow EPE vs reference oracle)",
@@ -231,7 +254,8 @@ def main():
             "epe_vs_oracle_m": epe,
             "roofline": {"bound": "hbm", "kernel": "scan_params_kernel + scan_preprocess_kernel<float,2>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms},
         }
         if not a.no_extra:
