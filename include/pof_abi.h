@@ -171,6 +171,12 @@ int pof_flow_errors(const float *pred, const float *target, const float *mask, i
 int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C, int n,
                          int kernel_size, int max_disp, pof_stream_t stream);
 
+/* Backward of pof_band_correlation (training Prototype end to end): given
+ * g_out = dL/d out [B][D][n] returns dL/d feat1, dL/d feat2 [B][C][n].  n <= 512. */
+int pof_band_correlation_backward(const float *feat1, const float *feat2, const float *g_out,
+                                  float *d_feat1, float *d_feat2, int B, int C, int n,
+                                  int kernel_size, int max_disp, pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A10 _SpatialAttention.forward (everything after the embedding conv)
  *                                   src/depracted/model/dr_spaam.py:163-217
@@ -182,6 +188,15 @@ int pof_band_correlation(const float *feat1, const float *feat2, float *out, int
 int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x, const float *tmpl,
                           int B, int N, int E, int F, int window, double alpha, float *band,
                           float *prob, float *out, pof_stream_t stream);
+
+/* Backward of pof_spatial_attention (training SpatialDROW through the gate).
+ * g_out = dL/d out [B][N][F]; g_band = dL/d band [B][N][w] or NULL.
+ * dsim [B][N][w] is scratch.  Outputs: d_emb_x, d_emb_t [B][N][E]; d_x, d_tmpl [B][N][F]. */
+int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const float *tmpl,
+                                   const float *prob, const float *g_out, const float *g_band,
+                                   int B, int N, int E, int F, int window, double alpha,
+                                   float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
+                                   float *d_tmpl, pof_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * A13 jump-distance segmentation + per-segment least squares

@@ -97,6 +97,53 @@ __global__ __launch_bounds__(kTile *kGroups) void band_corr_kernel(const float *
     }
 }
 
+// Backward: scatter form.  Each lane owns (channel, point i) and adds its
+// contributions to d_f1[c, clamp(i+k-hk)] and d_f2[c, clamp(j_d+k-hk)] in LDS
+// (ds_add_f32), the tile is then written out.  One workgroup = one sample x
+// kBwdCh channels x all n points (n <= kBwdMaxN).
+constexpr int kBwdCh = 8;
+constexpr int kBwdMaxN = 512;
+
+__global__ __launch_bounds__(256) void band_corr_bwd_kernel(const float *f1, const float *f2,
+                                                            const float *g_out, float *d_f1, float *d_f2,
+                                                            int C, int n, int K, int D)
+{
+    extern __shared__ float smem_f[];
+    float *s_g = smem_f;                 // [D][n]
+    float *s_d1 = s_g + D * n;           // [kBwdCh][n]
+    float *s_d2 = s_d1 + kBwdCh * n;     // [kBwdCh][n]
+    const int b = blockIdx.y, c0 = blockIdx.x * kBwdCh;
+    const int cc = min(kBwdCh, C - c0);
+    const int hk = K / 2, md = D / 2;
+    for (int e = threadIdx.x; e < D * n; e += blockDim.x) s_g[e] = g_out[(long long)b * D * n + e];
+    for (int e = threadIdx.x; e < 2 * kBwdCh * n; e += blockDim.x) s_d1[e] = 0.0f;
+    __syncthreads();
+    const float *g1 = f1 + ((long long)b * C + c0) * n;
+    const float *g2 = f2 + ((long long)b * C + c0) * n;
+    for (int e = threadIdx.x; e < cc * n; e += blockDim.x) {
+        const int c = e / n, i = e - c * n;
+        const float *r1 = g1 + (long long)c * n, *r2 = g2 + (long long)c * n;
+        for (int k = 0; k < K; ++k) {
+            const int a1 = min(max(i + k - hk, 0), n - 1);
+            const float v1 = r1[a1];
+            float acc1 = 0.0f;
+            for (int d = 0; d < D; ++d) {
+                const int j = min(max(i + d - md, 0), n - 1);
+                const int a2 = min(max(j + k - hk, 0), n - 1);
+                const float gv = s_g[d * n + i];
+                acc1 = fmaf(gv, r2[a2], acc1);
+                atomicAdd(&s_d2[c * n + a2], gv * v1);
+            }
+            atomicAdd(&s_d1[c * n + a1], acc1);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < cc * n; e += blockDim.x) {
+        d_f1[((long long)b * C + c0) * n + e] = s_d1[e];
+        d_f2[((long long)b * C + c0) * n + e] = s_d2[e];
+    }
+}
+
 template <int K>
 int launch_k(const float *f1, const float *f2, float *out, int B, int C, int n, int D, hipStream_t s)
 {
@@ -134,6 +181,24 @@ extern "C" int pof_band_correlation(const float *feat1, const float *feat2, floa
         default: rc = launch_k<5>(feat1, feat2, out, B, C, n, D, s); break;
     }
     if (rc != POF_OK) return rc;
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
+extern "C" int pof_band_correlation_backward(const float *feat1, const float *feat2, const float *g_out,
+                                             float *d_feat1, float *d_feat2, int B, int C, int n,
+                                             int kernel_size, int max_disp, pof_stream_t stream)
+{
+    if (!feat1 || !feat2 || !g_out || !d_feat1 || !d_feat2 || B < 0 || C < 1 || n < 1) return POF_E_BADARG;
+    if (kernel_size < 1 || kernel_size > kMaxK || (kernel_size & 1) == 0) return POF_E_SHAPE;
+    if (max_disp < 0 || 2 * max_disp + 1 > kMaxD) return POF_E_SHAPE;
+    if (n > kBwdMaxN) return POF_E_SHAPE;
+    if (B == 0) return POF_OK;
+    if (B > 65535) return POF_E_SHAPE;
+    const int D = 2 * max_disp + 1;
+    const size_t lds = (size_t)(D + 2 * kBwdCh) * n * sizeof(float);
+    band_corr_bwd_kernel<<<dim3((C + kBwdCh - 1) / kBwdCh, B), 256, lds, pof_stream(stream)>>>(
+        feat1, feat2, g_out, d_feat1, d_feat2, C, n, kernel_size, D);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

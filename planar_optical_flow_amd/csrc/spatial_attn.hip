@@ -57,10 +57,15 @@ __global__ __launch_bounds__(256) void attn_band_kernel(const float *emb_x, cons
     }
 }
 
-template <int W>
+// TRANS = false: forward merge   out[i] = alpha*x[i] + (1-alpha) * sum_k prob[i][k] * tmpl[i-HW+k]
+// TRANS = true : backward wrt the template, driven by the output gradient g (= `tmpl` argument):
+//                out[j]  = (1-alpha) * sum_k prob[j-HW+k][W-1-k] * g[j-HW+k]     (d tmpl)
+//                out2[j] = alpha * g[j]                                          (d x)
+template <int W, bool TRANS>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const float4 *tmpl,
-                                                         const float *prob, float4 *out, int N, int F4,
-                                                         int L, float alpha, float one_minus_alpha)
+                                                         const float *prob, float4 *out, float4 *out2,
+                                                         int N, int F4, int L, float alpha,
+                                                         float one_minus_alpha)
 {
     constexpr int HW = W / 2;
     const int col = blockIdx.x * 128 + threadIdx.x;
@@ -70,8 +75,9 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
     const int s1 = min(N, s0 + L);
     const long long sample = (long long)b * N;
     const float4 *T = tmpl + sample * F4 + col;
-    const float4 *X = x + sample * F4 + col;
+    const float4 *X = TRANS ? T : x + sample * F4 + col;
     float4 *O = out + sample * F4 + col;
+    float4 *O2 = TRANS ? out2 + sample * F4 + col : nullptr;
     const float *P = prob + sample * W;
     const int base = s0 - HW;
     const int rmax = s1 - 1 + HW;
@@ -87,23 +93,35 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
                 win[u] = (r >= 0 && r <= N - 1) ? T[(long long)r * F4] : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int i = r - HW;
                 if (i >= s0) {
-                    const float *p = P + (long long)i * W;
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                     for (int k = 0; k < W; ++k) {
-                        const float pk = p[k];
+                        float pk;
+                        if (TRANS) {
+                            const int src = i - HW + k;  // row whose window contains column i at slot W-1-k
+                            pk = (src >= 0 && src <= N - 1) ? P[(long long)src * W + (W - 1 - k)] : 0.0f;
+                        } else {
+                            pk = P[(long long)i * W + k];
+                        }
                         const float4 t = win[(u + k + 1) % W];
                         acc.x = fmaf(pk, t.x, acc.x);
                         acc.y = fmaf(pk, t.y, acc.y);
                         acc.z = fmaf(pk, t.z, acc.z);
                         acc.w = fmaf(pk, t.w, acc.w);
                     }
-                    const float4 xv = X[(long long)i * F4];
                     float4 o;
-                    o.x = alpha * xv.x + one_minus_alpha * acc.x;
-                    o.y = alpha * xv.y + one_minus_alpha * acc.y;
-                    o.z = alpha * xv.z + one_minus_alpha * acc.z;
-                    o.w = alpha * xv.w + one_minus_alpha * acc.w;
+                    if (TRANS) {
+                        const float4 gv = win[(u + HW + 1) % W];  // row i itself
+                        o = make_float4(one_minus_alpha * acc.x, one_minus_alpha * acc.y, one_minus_alpha * acc.z,
+                                        one_minus_alpha * acc.w);
+                        O2[(long long)i * F4] = make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w);
+                    } else {
+                        const float4 xv = X[(long long)i * F4];
+                        o.x = alpha * xv.x + one_minus_alpha * acc.x;
+                        o.y = alpha * xv.y + one_minus_alpha * acc.y;
+                        o.z = alpha * xv.z + one_minus_alpha * acc.z;
+                        o.w = alpha * xv.w + one_minus_alpha * acc.w;
+                    }
                     O[(long long)i * F4] = o;
                 }
             }
@@ -111,16 +129,109 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
     }
 }
 
-template <int W>
-void launch_merge(const float *x, const float *tmpl, const float *prob, float *out, int B, int N, int F,
-                  int L, double alpha, hipStream_t s)
+template <int W, bool TRANS>
+void launch_merge(const float *x, const float *tmpl, const float *prob, float *out, float *out2, int B, int N,
+                  int F, int L, double alpha, hipStream_t s)
 {
     const int F4 = F / 4;
     dim3 grid((F4 + 127) / 128, (N + L - 1) / L, B);
-    attn_merge_kernel<W><<<grid, 128, 0, s>>>(reinterpret_cast<const float4 *>(x),
-                                             reinterpret_cast<const float4 *>(tmpl), prob,
-                                             reinterpret_cast<float4 *>(out), N, F4, L, (float)alpha,
-                                             (float)(1.0 - alpha));
+    attn_merge_kernel<W, TRANS><<<grid, 128, 0, s>>>(
+        reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(tmpl), prob,
+        reinterpret_cast<float4 *>(out), reinterpret_cast<float4 *>(out2), N, F4, L, (float)alpha,
+        (float)(1.0 - alpha));
+}
+
+template <bool TRANS>
+int dispatch_merge(int W, const float *x, const float *tmpl, const float *prob, float *out, float *out2, int B,
+                   int N, int F, double alpha, hipStream_t s)
+{
+    // segment length: whole scan per lane when the batch alone fills the chip,
+    // shorter segments (more workgroups, a little halo re-read) for small batches
+    const long long colblocks = (F / 4 + 127) / 128;
+    int L = N;
+    while (L > 32 && colblocks * ((N + L - 1) / L) * B < 4096) L = (L + 1) / 2;
+    switch (W) {
+        case 1: launch_merge<1, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 3: launch_merge<3, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 5: launch_merge<5, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 7: launch_merge<7, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 9: launch_merge<9, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 11: launch_merge<11, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 13: launch_merge<13, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 15: launch_merge<15, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        default: return POF_E_SHAPE;
+    }
+    return POF_OK;
+}
+
+// ---- backward --------------------------------------------------------------------
+// One wave per point i: dp[k] = (1-alpha) <g[i], tmpl[i-HW+k]> over F (distinct columns
+// only), softmax backward ds = p (dp - sum p dp), dsim = ds + g_band -> dsim[b,i,k].
+__global__ __launch_bounds__(256) void attn_dsim_kernel(const float4 *g_out, const float4 *tmpl,
+                                                        const float *prob, const float *g_band, int N,
+                                                        int F4, int W, float one_minus_alpha, float *dsim)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (i >= N) return;
+    const int hw = W / 2;
+    const float4 *g = g_out + ((long long)b * N + i) * F4;
+    const float4 *T = tmpl + (long long)b * N * F4;
+    float mine = 0.0f;
+    for (int k = 0; k < W; ++k) {
+        const int j = i - hw + k;
+        float part = 0.0f;
+        if (j >= 0 && j <= N - 1) {
+            const float4 *tj = T + (long long)j * F4;
+            for (int c = lane; c < F4; c += 64) {
+                const float4 a = g[c], t = tj[c];
+                part = fmaf(a.x, t.x, part);
+                part = fmaf(a.y, t.y, part);
+                part = fmaf(a.z, t.z, part);
+                part = fmaf(a.w, t.w, part);
+            }
+        }
+        part = wave_sum_f32(part);
+        if (lane == k) mine = part * one_minus_alpha;
+    }
+    const bool slot = lane < W;
+    const long long o = ((long long)b * N + i) * W + lane;
+    const float p = slot ? prob[o] : 0.0f;
+    const float s = wave_sum_f32(p * mine);
+    if (slot) dsim[o] = p * (mine - s) + (g_band ? g_band[o] : 0.0f);
+}
+
+// d emb_x[i] = sum_k dsim[i,k] emb_t[clamp(i-hw+k)]
+// d emb_t[j] = sum over (i,k) with clamp(i-hw+k) == j of dsim[i,k] emb_x[i]
+__global__ __launch_bounds__(256) void attn_demb_kernel(const float *emb_x, const float *emb_t,
+                                                        const float *dsim, int N, int E, int W,
+                                                        float *d_emb_x, float *d_emb_t)
+{
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= N) return;
+    const int hw = W / 2;
+    const float *ex = emb_x + (long long)b * N * E;
+    const float *et = emb_t + (long long)b * N * E;
+    const float *ds = dsim + (long long)b * N * W;
+    for (int e = lane; e < E; e += 64) {
+        float ax = 0.0f, at = 0.0f;
+        for (int k = 0; k < W; ++k) {
+            const int j = min(max(r - hw + k, 0), N - 1);
+            ax = fmaf(ds[(long long)r * W + k], et[(long long)j * E + e], ax);
+        }
+        // rows whose window reaches column r (r plays the role of j)
+        for (int i = max(r - hw, 0); i <= min(r + hw, N - 1); ++i) {
+            for (int k = 0; k < W; ++k) {
+                const int j = min(max(i - hw + k, 0), N - 1);
+                if (j == r) at = fmaf(ds[(long long)i * W + k], ex[(long long)i * E + e], at);
+            }
+        }
+        d_emb_x[((long long)b * N + r) * E + e] = ax;
+        d_emb_t[((long long)b * N + r) * E + e] = at;
+    }
 }
 
 }  // namespace
@@ -142,21 +253,35 @@ extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, con
     hipStream_t s = pof_stream(stream);
     attn_band_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, N, E, W, band, prob);
     POF_CHECK_LAUNCH();
-    // segment length: whole scan per lane when the batch alone fills the chip,
-    // shorter segments (more workgroups, a little halo re-read) for small batches
-    const long long colblocks = (F / 4 + 127) / 128;
-    int L = N;
-    while (L > 32 && colblocks * ((N + L - 1) / L) * B < 4096) L = (L + 1) / 2;
-    switch (W) {
-        case 1: launch_merge<1>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 3: launch_merge<3>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 5: launch_merge<5>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 7: launch_merge<7>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 9: launch_merge<9>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 11: launch_merge<11>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        case 13: launch_merge<13>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-        default: launch_merge<15>(x, tmpl, prob, out, B, N, F, L, alpha, s); break;
-    }
+    const int rc = dispatch_merge<false>(W, x, tmpl, prob, out, nullptr, B, N, F, alpha, s);
+    if (rc != POF_OK) return rc;
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
+extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const float *tmpl,
+                                              const float *prob, const float *g_out, const float *g_band,
+                                              int B, int N, int E, int F, int window, double alpha,
+                                              float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
+                                              float *d_tmpl, pof_stream_t stream)
+{
+    if (!emb_x || !emb_t || !tmpl || !prob || !g_out || !dsim || !d_emb_x || !d_emb_t || !d_x || !d_tmpl)
+        return POF_E_BADARG;
+    if (B < 0 || N < 1 || E < 1 || F < 1) return POF_E_BADARG;
+    const int W = 2 * (window / 2) + 1;
+    if (W < 1 || W > kMaxW) return POF_E_SHAPE;
+    if (F % 4 != 0) return POF_E_SHAPE;
+    if (B == 0) return POF_OK;
+    if (B > 65535) return POF_E_SHAPE;
+    hipStream_t s = pof_stream(stream);
+    attn_dsim_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(reinterpret_cast<const float4 *>(g_out),
+                                                          reinterpret_cast<const float4 *>(tmpl), prob, g_band,
+                                                          N, F / 4, W, (float)(1.0 - alpha), dsim);
+    POF_CHECK_LAUNCH();
+    attn_demb_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, dsim, N, E, W, d_emb_x, d_emb_t);
+    POF_CHECK_LAUNCH();
+    const int rc = dispatch_merge<true>(W, nullptr, g_out, prob, d_tmpl, d_x, B, N, F, alpha, s);
+    if (rc != POF_OK) return rc;
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

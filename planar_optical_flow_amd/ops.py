@@ -377,6 +377,50 @@ def spatial_attention(emb_x, emb_t, x, tmpl, alpha=0.5, window_size=11, out=None
     return out, band, prob
 
 
+def band_correlation_backward(feat1, feat2, g_out, kernel_size=3, max_displacement=5):
+    """Gradients of band_correlation wrt feat1 / feat2."""
+    feat1 = _dev(feat1, torch.float32, "feat1")
+    feat2 = _dev(feat2, torch.float32, "feat2")
+    g_out = _dev(g_out, torch.float32, "g_out")
+    B, Cc, n = feat1.shape
+    if tuple(g_out.shape) != (B, 2 * max_displacement + 1, n):
+        raise ValueError("g_out must be [B, 2*max_displacement+1, n]")
+    d1, d2 = torch.empty_like(feat1), torch.empty_like(feat2)
+    with torch.cuda.device(feat1.device):
+        for s in range(0, B, 65535):
+            m = min(65535, B - s)
+            _lib.call("pof_band_correlation_backward", _ptr(feat1[s:s + m]), _ptr(feat2[s:s + m]),
+                      _ptr(g_out[s:s + m]), _ptr(d1[s:s + m]), _ptr(d2[s:s + m]), m, Cc, n, int(kernel_size),
+                      int(max_displacement), _stream())
+    return d1, d2
+
+
+def spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out, g_band, alpha, window_size):
+    """Gradients of spatial_attention: -> (d_emb_x, d_emb_t, d_x, d_tmpl)."""
+    emb_x = _dev(emb_x, torch.float32, "emb_x")
+    emb_t = _dev(emb_t, torch.float32, "emb_t")
+    tmpl = _dev(tmpl, torch.float32, "tmpl")
+    prob = _dev(prob, torch.float32, "prob")
+    g_out = _dev(g_out, torch.float32, "g_out")
+    if g_band is not None:
+        g_band = _dev(g_band, torch.float32, "g_band")
+    B, N, E = emb_x.shape
+    F = tmpl.numel() // (B * N)
+    dev = tmpl.device
+    dsim = torch.empty_like(prob)
+    dex, det = torch.empty_like(emb_x), torch.empty_like(emb_t)
+    dx, dt = torch.empty_like(tmpl), torch.empty_like(tmpl)
+    with torch.cuda.device(dev):
+        for s in range(0, B, 65535):
+            m = min(65535, B - s)
+            _lib.call("pof_spatial_attention_backward", _ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]),
+                      _ptr(tmpl[s:s + m]), _ptr(prob[s:s + m]), _ptr(g_out[s:s + m]),
+                      _ptr(g_band[s:s + m]) if g_band is not None else None, m, N, E, F, int(window_size),
+                      float(alpha), _ptr(dsim[s:s + m]), _ptr(dex[s:s + m]), _ptr(det[s:s + m]),
+                      _ptr(dx[s:s + m]), _ptr(dt[s:s + m]), _stream())
+    return dex, det, dx, dt
+
+
 def segment_features(ranges, tab, jump_dist=0.5, max_seg=None):
     """A13: ranges [B,N] float32 -> (seg_id [B,N] int32, num_seg [B] int32, feat [B,max_seg,16] f64)."""
     ranges = _dev(ranges, torch.float32, "ranges")

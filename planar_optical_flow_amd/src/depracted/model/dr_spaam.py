@@ -7,8 +7,8 @@ kernel_size=n_pts) + BatchNorm1d + LeakyReLU(0.1); same state-dict keys).  The
 embedding stays a dense MIOpen/rocBLAS op; the windowed similarity, the masked
 softmax and the weighted template merge -- a full N x N GEMM pair in the
 reference -- run as two banded HIP launches (pof_spatial_attention).
-Forward only in this round (inference / frozen-detector flow training, which is
-how FlowDROW_pretrained uses it, :297-298).
+Forward and backward are HIP (the backward reuses the register-ring merge kernel in
+transposed form), so SpatialDROW trains through the gate.
 """
 import torch
 import torch.nn as nn
@@ -24,15 +24,21 @@ def flow_loss(pred, target, mask=None):
 class _WindowedAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb_x, emb_t, x, tmpl, alpha, window):
-        B, N = x.shape[:2]
-        out, band, _ = ops.spatial_attention(emb_x.contiguous().float(), emb_t.contiguous().float(),
-                                             x.contiguous().float(), tmpl.contiguous().float(), alpha, window)
-        ctx.mark_non_differentiable(band)
+        ex, et = emb_x.contiguous().float(), emb_t.contiguous().float()
+        xx, tt = x.contiguous().float(), tmpl.contiguous().float()
+        out, band, prob = ops.spatial_attention(ex, et, xx, tt, alpha, window)
+        ctx.save_for_backward(ex, et, tt, prob)
+        ctx.cfg = (alpha, window)
         return out, band
 
     @staticmethod
-    def backward(ctx, g_out, g_band):  # pragma: no cover
-        raise NotImplementedError("spatial attention backward is not implemented yet (forward-only HIP path)")
+    def backward(ctx, g_out, g_band):
+        ex, et, tt, prob = ctx.saved_tensors
+        alpha, window = ctx.cfg
+        gb = None if g_band is None else g_band.contiguous().float()
+        dex, det, dx, dt = ops.spatial_attention_backward(ex, et, tt, prob, g_out.contiguous().float(), gb,
+                                                          alpha, window)
+        return dex, det, dx.view_as(g_out), dt.view_as(g_out), None, None
 
 
 class _SpatialAttention(nn.Module):

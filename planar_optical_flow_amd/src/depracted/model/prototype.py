@@ -3,8 +3,8 @@ the banded patch correlation ``Prototype._fusion`` (:118-156) and the per-sample
 EPE ``flow_loss`` (:27-32).  The 1-D conv encoder/decoder around them is plain
 ``torch.nn`` in the reference and stays on MIOpen.
 
-Forward only in this round: the correlation is exposed as an autograd Function so
-that it composes with torch modules, and asks loudly if a backward is requested.
+The correlation is an autograd Function (HIP forward and backward), so it composes
+with the torch encoder/decoder for end-to-end training.
 """
 import torch
 
@@ -14,12 +14,16 @@ from planar_optical_flow_amd import ops
 class _BandCorrelation(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat1, feat2, kernel_size, max_displacement):
-        return ops.band_correlation(feat1.contiguous().float(), feat2.contiguous().float(), kernel_size,
-                                    max_displacement)
+        f1, f2 = feat1.contiguous().float(), feat2.contiguous().float()
+        ctx.save_for_backward(f1, f2)
+        ctx.cfg = (kernel_size, max_displacement)
+        return ops.band_correlation(f1, f2, kernel_size, max_displacement)
 
     @staticmethod
-    def backward(ctx, grad):  # pragma: no cover
-        raise NotImplementedError("band correlation backward is not implemented yet (forward-only HIP path)")
+    def backward(ctx, grad):
+        f1, f2 = ctx.saved_tensors
+        d1, d2 = ops.band_correlation_backward(f1, f2, grad.contiguous().float(), *ctx.cfg)
+        return d1, d2, None, None
 
 
 def fusion(feat1, feat2, kernel_size=3, max_displacement=5):

@@ -416,3 +416,76 @@ def test_rotate_iou_vs_oracle(ops):
         want = R.rotate_iou(bx[gidx], qx[gidx][:kv[gidx]])
         np.testing.assert_allclose(got[gidx][:, :kv[gidx]], want, rtol=0, atol=1e-5)
         assert np.all(got[gidx][:, kv[gidx]:] == 0)
+
+
+# ---------------------------------------------------------------- A9 / A10 backward
+def _torch_fusion(f1, f2, K=3, md=5):
+    """Plain-torch float32 restatement of Prototype._fusion (prototype.py:118-156):
+    patch gather -> full n x n matmul -> band gather.  Reference for autograd."""
+    B, C, n = f1.shape
+    hk = K // 2
+    ids = (torch.arange(n, device=f1.device)[:, None] + torch.arange(-hk, hk + 1, device=f1.device)[None]).clamp(0, n - 1)
+    p1 = f1[:, :, ids.reshape(-1)].reshape(B, C, n, K).permute(0, 1, 3, 2).reshape(B, C * K, n)
+    p2 = f2[:, :, ids.reshape(-1)].reshape(B, C, n, K).permute(0, 1, 3, 2).reshape(B, C * K, n)
+    corr = torch.matmul(p1.permute(0, 2, 1), p2)
+    j = (torch.arange(n, device=f1.device)[:, None] + torch.arange(-md, md + 1, device=f1.device)[None]).clamp(0, n - 1)
+    i = torch.arange(n, device=f1.device)[:, None].expand_as(j)
+    return corr[:, i.reshape(-1), j.reshape(-1)].reshape(B, n, -1).permute(0, 2, 1)
+
+
+def _torch_attention(ex, et, x, t, alpha, w):
+    """Plain-torch float32 restatement of _SpatialAttention.forward after the
+    embedding (dr_spaam.py:183-215)."""
+    B, N, _ = ex.shape
+    hw = int(w / 2)
+    cols = (torch.arange(N, device=ex.device)[:, None] + torch.arange(-hw, hw + 1, device=ex.device)[None]).clamp(0, N - 1)
+    rows = torch.arange(N, device=ex.device)[:, None].expand_as(cols)
+    mask = torch.zeros(N, N, device=ex.device)
+    mask[rows.reshape(-1), cols.reshape(-1)] = 1.0
+    sim = torch.matmul(ex, et.permute(0, 2, 1))
+    band = sim[:, rows.reshape(-1), cols.reshape(-1)].reshape(B, N, -1)
+    s = sim - 1e10 * (1.0 - mask)
+    e = torch.exp(s - s.max(dim=-1, keepdim=True)[0]) * mask
+    p = e / e.sum(dim=-1, keepdim=True)
+    return alpha * x + (1.0 - alpha) * torch.matmul(p, t), band
+
+
+def test_band_correlation_backward_vs_autograd(ops):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd"))
+    from src.depracted.model.prototype import fusion
+    torch.manual_seed(3)
+    for (B, C, n, K, md) in ((2, 20, 57, 3, 5), (1, 9, 130, 3, 3)):
+        f1 = torch.randn(B, C, n, device=DEV, requires_grad=True)
+        f2 = torch.randn(B, C, n, device=DEV, requires_grad=True)
+        gout = torch.randn(B, 2 * md + 1, n, device=DEV)
+        (fusion(f1, f2, K, md) * gout).sum().backward()
+        g1, g2 = f1.grad.clone(), f2.grad.clone()
+        f1.grad = f2.grad = None
+        (_torch_fusion(f1, f2, K, md) * gout).sum().backward()
+        np.testing.assert_allclose(g1.cpu().numpy(), f1.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(g2.cpu().numpy(), f2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_spatial_attention_backward_vs_autograd(ops):
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd"))
+    from src.depracted.model.dr_spaam import _WindowedAttention
+    torch.manual_seed(4)
+    for (B, N, E, F, alpha, w) in ((2, 37, 128, 64, 0.5, 11), (1, 450, 128, 3584, 0.3, 7)):
+        leaves = [torch.randn(B, N, E, device=DEV) * 0.3, torch.randn(B, N, E, device=DEV) * 0.3,
+                  torch.randn(B, N, F, device=DEV), torch.randn(B, N, F, device=DEV)]
+        for t in leaves:
+            t.requires_grad_(True)
+        g_out = torch.randn(B, N, F, device=DEV)
+        g_band = torch.randn(B, N, 2 * int(w / 2) + 1, device=DEV)
+        out, band = _WindowedAttention.apply(*leaves, alpha, w)
+        ((out * g_out).sum() + (band * g_band).sum()).backward()
+        got = [t.grad.clone() for t in leaves]
+        for t in leaves:
+            t.grad = None
+        out_r, band_r = _torch_attention(*leaves, alpha, w)
+        np.testing.assert_allclose(out.detach().cpu().numpy(), out_r.detach().cpu().numpy(), rtol=1e-4, atol=1e-5)
+        ((out_r * g_out).sum() + (band_r * g_band).sum()).backward()
+        for name, a, t in zip(("d_emb_x", "d_emb_t", "d_x", "d_tmpl"), got, leaves):
+            np.testing.assert_allclose(a.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-4, err_msg=name)
