@@ -52,6 +52,10 @@ int pof_laser_phi(double angle_inc, int num_pts, double *tab /* [3*N] */, pof_st
  *   get_displacement_from_odometry      src/utils/utils.py:639-662  (kind 0)
  *   get_flow_target                     src/utils/utils.py:204-229  (kind 1)
  *   get_velocity_from_odometry          src/utils/utils.py:609-636  (kind 2)
+ *   data_prepare.get_flow_target        bin/data_prepare.py:29-47   (kind 3; odom0 = odometry
+ *                                       difference (dx,dy,dphi), odom1[0] = dt)
+ *   scan-pair alignment                 src/utils/dataset.py:76-93  (kind 4; `flow` receives the
+ *                                       transformed points; odom0 = (dx,dy,dphi), odom1[0] = scan_dir)
  *   global_to_canonical_flow            src/utils/utils.py:62-75    (canonical != 0)
  *   closest_detection / get_regression_target   src/utils/utils.py:147-185, 232-256
  *   _get_dynamic_mask / _get_valid_point_mask   src/utils/dataset_dr_spaam.py:511-529

@@ -94,13 +94,63 @@ __device__ void motion_params(int kind, const double *o0, const double *o1, doub
         mot[4] = fma(ty, -sA, tx * cA);
         mot[5] = fma(ty, cA, tx * sA);
         mot[6] = 0.0;
-    } else {
+    } else if (kind == 2) {
         // get_velocity_from_odometry: float32 R1, cross matrix dphi*[[0,-1],[1,0]]
         const float c1 = (float)cB, s1 = (float)sB;
         mot[0] = mot[1] = mot[2] = mot[3] = 0.0;
         mot[4] = fma((double)c1, tx, (double)s1 * ty);
         mot[5] = fma((double)(-s1), tx, (double)c1 * ty);
         mot[6] = o1[2] - o0[2];
+    } else if (kind == 3) {
+        // bin/data_prepare.get_flow_target (:29-47): o0 = odometry difference (dx, dy, dphi),
+        // o1[0] = dt.  v = dxy/(dt+reg), w = dphi/(dt+reg); flow = (w x r + v) * dt
+        const double dt = o1[0], den = dt + 1e-6;
+        mot[0] = o0[2] / den;   // w
+        mot[1] = o0[0] / den;   // vx
+        mot[2] = o0[1] / den;   // vy
+        mot[3] = dt;
+        mot[4] = mot[5] = mot[6] = 0.0;
+    } else {
+        // scan-pair alignment (src/utils/dataset.py:76-93): o0 = (dx, dy, dphi), o1[0] = scan_dir
+        // (sA,cA) = sincos(dphi), (sB,cB) = sincos(scan_dir); float32 matrices
+        const float c = (float)cA, sn = (float)sA, cd = (float)cB, sd = (float)sB;
+        mot[0] = (double)c; mot[1] = (double)sn; mot[2] = (double)(-sn); mot[3] = (double)c;
+        mot[4] = fma(o0[1], (double)(-sd), o0[0] * (double)cd);
+        mot[5] = fma(o0[1], (double)cd, o0[0] * (double)sd);
+        mot[6] = 0.0;
+    }
+}
+
+// angle whose sincos lane `which` (0/1) of a sample evaluates
+__device__ __forceinline__ double motion_angle(int kind, int which, const double *o0, const double *o1)
+{
+    if (kind == 1) return which ? o1[2] - o0[2] : o0[2];
+    if (kind == 4) return which ? o1[0] : o0[2];
+    return which ? o1[2] : o0[2];
+}
+
+// per-point evaluation shared by the streaming and the xy-input kernels
+__device__ __forceinline__ void apply_motion(int kind, double px, double py, double m0, double m1, double m2,
+                                             double m3, double t0, double t1, double dph, double &fx,
+                                             double &fy)
+{
+    if (kind == 0) {
+        fx = fma(py, m1, px * m0) - t0;
+        fy = fma(py, m3, px * m2) - t1;
+    } else if (kind == 1) {
+        fx = (fma(py, m1, px * m0) - t0) - px;
+        fy = (fma(py, m3, px * m2) - t1) - py;
+    } else if (kind == 2) {
+        // -lin - xy @ cross^T, cross^T = [[0, dphi], [-dphi, 0]]
+        fx = -t0 - (py * -dph);
+        fy = -t1 - (px * dph);
+    } else if (kind == 3) {
+        // np.cross([0,0,w],[x,y,0])[:2] = (0*0 - w*y, w*x - 0*0); + v; * dt
+        fx = ((0.0 - m0 * py) + m1) * m3;
+        fy = ((m0 * px - 0.0) + m2) * m3;
+    } else {
+        fx = fma(py, m1, px * m0) + t0;
+        fy = fma(py, m3, px * m2) + t1;
     }
 }
 
@@ -136,7 +186,7 @@ __global__ __launch_bounds__(256) void scan_params_kernel(PreArgs a)
         const double *o0 = a.odom0 + 3 * b, *o1 = a.odom1 + 3 * b;
         double s = 0.0, c = 1.0;
         if (a.flow) {
-            const double ang = which ? ((a.flow_kind == 1) ? o1[2] - o0[2] : o1[2]) : o0[2];
+            const double ang = motion_angle(a.flow_kind, which, o0, o1);
             sincos(ang, &s, &c);
         }
         // partner lane (t ^ 1) holds the other angle of the same sample
@@ -311,19 +361,7 @@ __global__ __launch_bounds__(kThreads, 8) void scan_preprocess_kernel(PreArgs a)
 #pragma unroll
             for (int k = 0; k < PTS; ++k) {
                 double fx, fy;
-                if (a.flow_kind == 0) {
-                    fx = fma(py[k], m1, px[k] * m0) - t0;
-                    fy = fma(py[k], m3, px[k] * m2) - t1;
-                } else if (a.flow_kind == 1) {
-                    double x1 = fma(py[k], m1, px[k] * m0) - t0;
-                    double y1 = fma(py[k], m3, px[k] * m2) - t1;
-                    fx = x1 - px[k];
-                    fy = y1 - py[k];
-                } else {
-                    // -lin - xy @ cross^T, cross^T = [[0, dphi], [-dphi, 0]]
-                    fx = -t0 - (py[k] * -dph);
-                    fy = -t1 - (px[k] * dph);
-                }
+                apply_motion(a.flow_kind, px[k], py[k], m0, m1, m2, m3, t0, t1, dph, fx, fy);
                 if (a.canonical) {
                     // einsum('ijk,ik->ij'): c*fx + (-s)*fy ; s*fx + c*fy, no fusion
                     double gx = cs[k] * fx + (-sn[k]) * fy;
@@ -547,7 +585,7 @@ __global__ __launch_bounds__(256) void flow_from_xy_kernel(const double *xy, con
     const double *o0 = odom0 + 3 * b, *o1 = odom1 + 3 * b;
     if (threadIdx.x < 2) {
         const int which = threadIdx.x;
-        const double ang = which ? ((kind == 1) ? o1[2] - o0[2] : o1[2]) : o0[2];
+        const double ang = motion_angle(kind, which, o0, o1);
         sincos(ang, &s_sc[2 * which], &s_sc[2 * which + 1]);
     }
     __syncthreads();
@@ -557,16 +595,7 @@ __global__ __launch_bounds__(256) void flow_from_xy_kernel(const double *xy, con
         const long long p = (long long)b * N + i;
         const double px = xy[2 * p], py = xy[2 * p + 1];
         double fx, fy;
-        if (kind == 0) {
-            fx = fma(py, s_mot[1], px * s_mot[0]) - s_mot[4];
-            fy = fma(py, s_mot[3], px * s_mot[2]) - s_mot[5];
-        } else if (kind == 1) {
-            fx = (fma(py, s_mot[1], px * s_mot[0]) - s_mot[4]) - px;
-            fy = (fma(py, s_mot[3], px * s_mot[2]) - s_mot[5]) - py;
-        } else {
-            fx = -s_mot[4] - (py * -s_mot[6]);
-            fy = -s_mot[5] - (px * s_mot[6]);
-        }
+        apply_motion(kind, px, py, s_mot[0], s_mot[1], s_mot[2], s_mot[3], s_mot[4], s_mot[5], s_mot[6], fx, fy);
         if (canonical) {
             const double c = tab[N + 2 * i], sn = tab[N + 2 * i + 1];
             const double gx = c * fx + (-sn) * fy, gy = sn * fx + c * fy;
@@ -594,7 +623,7 @@ extern "C" int pof_flow_from_xy(const double *xy, const double *odom0, const dou
                                 pof_stream_t stream)
 {
     if (!xy || !odom0 || !odom1 || !flow || B < 0 || N < 1) return POF_E_BADARG;
-    if (flow_kind < 0 || flow_kind > 2) return POF_E_BADARG;
+    if (flow_kind < 0 || flow_kind > 4) return POF_E_BADARG;
     if (canonical && !tab) return POF_E_BADARG;
     if (B == 0) return POF_OK;
     flow_from_xy_kernel<<<B, 256, 0, pof_stream(stream)>>>(xy, odom0, odom1, flow_kind, canonical, tab, flow, N);
@@ -660,7 +689,7 @@ extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride,
 {
     if (!ranges || !tab || B < 0 || N < 1 || D < 0) return POF_E_BADARG;
     if (flow && (!odom0 || !odom1)) return POF_E_BADARG;
-    if (flow_kind < 0 || flow_kind > 2) return POF_E_BADARG;
+    if (flow_kind < 0 || flow_kind > 4) return POF_E_BADARG;
     if (det_offsets && (!assoc_radius || !labels || !dyn_radius)) return POF_E_BADARG;
     if (det_offsets && D > 0 && (!det_rphi || !det_cls)) return POF_E_BADARG;
     if (sample_stride < N) return POF_E_SHAPE;

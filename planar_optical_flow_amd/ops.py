@@ -80,7 +80,7 @@ class DetCSR:
                       torch.from_numpy(c).to(device))
 
 
-FLOW_DISPLACEMENT, FLOW_TARGET, FLOW_VELOCITY = 0, 1, 2
+FLOW_DISPLACEMENT, FLOW_TARGET, FLOW_VELOCITY, FLOW_PREPARED, ALIGN_NEXT_SCAN = 0, 1, 2, 3, 4
 
 
 def scan_preprocess_workspace_bytes(B, D):

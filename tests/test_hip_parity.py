@@ -489,3 +489,23 @@ def test_spatial_attention_backward_vs_autograd(ops):
         ((out_r * g_out).sum() + (band_r * g_band).sum()).backward()
         for name, a, t in zip(("d_emb_x", "d_emb_t", "d_x", "d_tmpl"), got, leaves):
             np.testing.assert_allclose(a.cpu().numpy(), t.grad.cpu().numpy(), rtol=2e-4, atol=2e-4, err_msg=name)
+
+
+def test_a3c_prepared_flow_and_alignment(ops, geo):
+    """bin/data_prepare.get_flow_target (golden) and the scan-pair alignment of
+    src/utils/dataset.py:76-93 (oracle restatement)."""
+    g, sb = geo
+    tab = ops.phi_table()
+    phi = R.laser_phi()
+    odt, od = float(g["a3c_odom_t"]), g["a3c_odom"]
+    o0 = T(od[None])
+    o1 = T(np.array([[odt, 0.0, 0.0]]))
+    out = ops.scan_preprocess(T(sb.scans[0:1, -1]), tab, o0, o1, flow_kind=ops.FLOW_PREPARED, canonical=False,
+                              out_dtype=torch.float64, want=("flow",))
+    np.testing.assert_allclose(out["flow"][0].cpu().numpy(), g["a3c_flow"], rtol=0, atol=1e-14)
+    scan_dir = 0.4
+    o1 = T(np.array([[scan_dir, 0.0, 0.0]]))
+    out = ops.scan_preprocess(T(sb.scans[1:2, -1]), tab, o0, o1, flow_kind=ops.ALIGN_NEXT_SCAN, canonical=False,
+                              out_dtype=torch.float64, want=("flow",))
+    want = R.align_next_scan(sb.scans[1, -1], phi, od, scan_dir)
+    np.testing.assert_allclose(out["flow"][0].cpu().numpy(), want, rtol=0, atol=1e-12)
