@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--ring", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="graph: params launch of batch i+1 on a second stream (measured: no gain, see DESIGN.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -158,9 +160,9 @@ def main():
         ring.append((scans, o0, o1, det, outs, ws))
     want = ("flow", "target_cls", "target_reg", "exclude_mask")
 
-    def step(i):
+    def step(i, phases=3):
         scans, o0, o1, det, outs, ws = ring[i % a.ring]
-        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws)
+        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
 
     def barrier():
         torch.cuda.synchronize()
@@ -180,8 +182,27 @@ def main():
         torch.cuda.synchronize()
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            for i in range(a.ring):
-                step(i)
+            if not a.pipeline:
+                for i in range(a.ring):
+                    step(i)
+            else:
+                # two-stream software pipeline over the independent batches of the ring: the
+                # tiny per-sample params launch of batch i+1 runs under the streaming launch of
+                # batch i (each batch has its own workspace; an event orders params(i) -> main(i))
+                main = torch.cuda.current_stream()
+                side2 = torch.cuda.Stream()
+                side2.wait_stream(main)
+                evs = []
+                with torch.cuda.stream(side2):
+                    for i in range(a.ring):
+                        step(i, phases=1)
+                        ev = torch.cuda.Event()
+                        ev.record(side2)
+                        evs.append(ev)
+                for i in range(a.ring):
+                    main.wait_event(evs[i])
+                    step(i, phases=2)
+                main.wait_stream(side2)
 
     def run(k):
         if graph is not None:
@@ -249,7 +270,8 @@ def main():
                                    "(A1-A7 fused: xy, displacement flow, canonical frame, association, "
                                    "regression target, exclude mask), float32 outputs" % B,
                        "global_batch": world * B, "ring_batches": a.ring,
-                       "launch": "hipGraph replay" if graph is not None else "eager",
+                       "launch": ("eager" if graph is None else
+                                  "hipGraph replay" + (", params launch of batch i+1 on a second stream" if a.pipeline else "")),
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "epe_vs_oracle_m": epe,
             "roofline": {"bound": "hbm", "kernel": "scan_params_kernel + scan_preprocess_kernel<float,2>",

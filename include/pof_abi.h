@@ -94,6 +94,20 @@ int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int
                         float *target_reg, float *dyn_mask, float *valid_mask, float *exclude_mask,
                         void *workspace, size_t workspace_bytes, pof_stream_t stream);
 
+/* Same call split in its two launches, for callers that pipeline independent
+ * batches on two streams (params of batch i+1 under the streaming launch of
+ * batch i): phases = 1 runs only the per-sample params launch (fills the
+ * workspace), phases = 2 only the streaming launch (workspace must have been
+ * filled for these inputs), phases = 3 both (= pof_scan_preprocess). */
+int pof_scan_preprocess_phase(const float *ranges, long long sample_stride, int B, int N,
+                              const double *tab, const double *odom0, const double *odom1,
+                              int flow_kind, int canonical, int out_f64, void *xy, void *flow,
+                              const int32_t *det_offsets, const double *det_rphi, const uint8_t *det_cls,
+                              int D, const double *assoc_radius, const int32_t *labels,
+                              const double *dyn_radius, int64_t *closest, int64_t *target_cls,
+                              float *target_reg, float *dyn_mask, float *valid_mask, float *exclude_mask,
+                              void *workspace, size_t workspace_bytes, int phases, pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A3 on caller-supplied scanner-frame points (the reference's own signature):
  *   get_displacement_from_odometry(scan1_xy, odom0, odom1)   src/utils/utils.py:639-662

@@ -25,6 +25,8 @@ SIGNATURES = {
     "pof_error_string": (C.c_char_p, [_i]),
     "pof_laser_phi": (_i, [_d, _i, _p, _p]),
     "pof_scan_preprocess_workspace_bytes": (_sz, [_i, _i]),
+    "pof_scan_preprocess_phase": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
+                                       _p, _p, _p, _p, _p, _p, _p, _sz, _i, _p]),
     "pof_scan_preprocess": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                                  _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_flow_from_xy": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _p]),

@@ -677,16 +677,17 @@ extern "C" size_t pof_scan_preprocess_workspace_bytes(int B, int D)
     return ((size_t)B * kRecStride + (size_t)D * kDetStride) * sizeof(double) + 64;
 }
 
-extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,
-                                   const double *tab, const double *odom0, const double *odom1,
-                                   int flow_kind, int canonical, int out_f64, void *xy, void *flow,
-                                   const int32_t *det_offsets, const double *det_rphi,
-                                   const uint8_t *det_cls, int D, const double *assoc_radius,
-                                   const int32_t *labels, const double *dyn_radius, int64_t *closest,
-                                   int64_t *target_cls, float *target_reg, float *dyn_mask,
-                                   float *valid_mask, float *exclude_mask, void *workspace,
-                                   size_t workspace_bytes, pof_stream_t stream)
+extern "C" int pof_scan_preprocess_phase(const float *ranges, long long sample_stride, int B, int N,
+                                         const double *tab, const double *odom0, const double *odom1,
+                                         int flow_kind, int canonical, int out_f64, void *xy, void *flow,
+                                         const int32_t *det_offsets, const double *det_rphi,
+                                         const uint8_t *det_cls, int D, const double *assoc_radius,
+                                         const int32_t *labels, const double *dyn_radius, int64_t *closest,
+                                         int64_t *target_cls, float *target_reg, float *dyn_mask,
+                                         float *valid_mask, float *exclude_mask, void *workspace,
+                                         size_t workspace_bytes, int phases, pof_stream_t stream)
 {
+    if ((phases & 3) == 0 || (phases & ~3)) return POF_E_BADARG;
     if (!ranges || !tab || B < 0 || N < 1 || D < 0) return POF_E_BADARG;
     if (flow && (!odom0 || !odom1)) return POF_E_BADARG;
     if (flow_kind < 0 || flow_kind > 4) return POF_E_BADARG;
@@ -721,11 +722,12 @@ extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride,
     a.ws_rec = reinterpret_cast<double *>(base);
     a.ws_det = a.ws_rec + (size_t)B * kRecStride;
     hipStream_t s = pof_stream(stream);
-    if (need_ws) {
+    if (need_ws && (phases & 1)) {
         const int total = 2 * B + a.D + (det_offsets ? B * kInline : 0);
         scan_params_kernel<<<(total + 255) / 256, 256, 0, s>>>(a);
         POF_CHECK_LAUNCH();
     }
+    if (!(phases & 2)) return POF_OK;
     // float2 row loads need 8-byte aligned rows
     auto al16 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     const bool vec2 = (N % 2 == 0) && (sample_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(ranges) & 7) == 0) &&
@@ -749,6 +751,22 @@ extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride,
     }
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+
+extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,
+                                   const double *tab, const double *odom0, const double *odom1,
+                                   int flow_kind, int canonical, int out_f64, void *xy, void *flow,
+                                   const int32_t *det_offsets, const double *det_rphi,
+                                   const uint8_t *det_cls, int D, const double *assoc_radius,
+                                   const int32_t *labels, const double *dyn_radius, int64_t *closest,
+                                   int64_t *target_cls, float *target_reg, float *dyn_mask,
+                                   float *valid_mask, float *exclude_mask, void *workspace,
+                                   size_t workspace_bytes, pof_stream_t stream)
+{
+    return pof_scan_preprocess_phase(ranges, sample_stride, B, N, tab, odom0, odom1, flow_kind, canonical, out_f64,
+                                     xy, flow, det_offsets, det_rphi, det_cls, D, assoc_radius, labels, dyn_radius,
+                                     closest, target_cls, target_reg, dyn_mask, valid_mask, exclude_mask, workspace,
+                                     workspace_bytes, 3, stream);
 }
 
 extern "C" int pof_rotate_flow(const void *flow_in, void *flow_out, const double *tab, int B, int N,

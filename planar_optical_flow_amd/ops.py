@@ -90,12 +90,15 @@ def scan_preprocess_workspace_bytes(B, D):
 def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLOW_DISPLACEMENT,
                     canonical=True, out_dtype=torch.float32, want=("flow",),
                     assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3), dyn_radius=(2.5, 2.0, 2.0),
-                    out=None, workspace=None):
+                    out=None, workspace=None, phases=3):
     """A2-A7 fused, one launch.
 
     scans: [B,T,N] (the last row of each window is the current scan) or [B,N].
     want: subset of {"xy","flow","closest","target_cls","target_reg","dyn_mask",
           "valid_mask","exclude_mask"}.  `out` may hold preallocated tensors.
+    phases: 3 = both launches; 1 = only the per-sample params launch into
+          `workspace`, 2 = only the streaming launch (for two-stream pipelining of
+          independent batches; B <= 65535 in that mode).
     Returns a dict of device tensors.
     """
     scans = _dev(scans, torch.float32, "scans")
@@ -172,14 +175,15 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
                 return None if t is None else C.c_void_p(t.data_ptr() + s * per * t.element_size())
 
             _lib.call(
-                "pof_scan_preprocess", C.c_void_p(base + 4 * s * stride), stride, n, N, _ptr(tab),
+                "pof_scan_preprocess_phase", C.c_void_p(base + 4 * s * stride), stride, n, N, _ptr(tab),
                 sl(odom0, 3) if "flow" in want else None, sl(odom1, 3) if "flow" in want else None,
                 int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
                 sl(xy, 2 * N), sl(flow, 2 * N),
                 sl(dets.offsets, 1) if need_det else None,
                 _ptr(dets.rphi) if need_det else None, _ptr(dets.cls) if need_det else None, D,
                 ar, lb, dr, sl(closest, N), sl(tcls, N), sl(treg, 2 * N), sl(dyn, N), sl(val, N),
-                sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(), _stream())
+                sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(), int(phases),
+                _stream())
     return out
 
 
