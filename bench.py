@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
     ap.add_argument("--pipeline", action="store_true",
                     help="graph: params launch of batch i+1 on a second stream (measured: no gain, see DESIGN.md)")
+    ap.add_argument("--no-chain", dest="chained", action="store_false",
+                    help="two launches per step (params + streaming) instead of the chained single launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
@@ -162,7 +164,17 @@ def main():
 
     def step(i, phases=3):
         scans, o0, o1, det, outs, ws = ring[i % a.ring]
-        ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
+        if a.chained and phases == 3:
+            # one launch: stream batch i (its params were produced by the previous step's launch)
+            # and evaluate the params of batch i+1 on extra workgroups of the same grid
+            _, n0, n1, ndet, _, nws = ring[(i + 1) % a.ring]
+            ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws,
+                                next_batch={"odom0": n0, "odom1": n1, "dets": ndet, "workspace": nws})
+        else:
+            ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
+
+    if a.chained:
+        step(0, phases=1)  # prime the chain: params of ring slot 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -249,7 +261,8 @@ def main():
         bytes_per_scan = 4 * N + (8 + 8 + 8 + 4) * N
         launch_ms = dev_ms / a.steps
         achieved = bytes_per_scan * B / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(("scan_params_kernel", "scan_preprocess_kernel"))
+        traffic, traffic_src = pmc_traffic(("scan_preprocess_chain_kernel",) if a.chained
+                                           else ("scan_params_kernel", "scan_preprocess_kernel"))
         if B != BATCH:
             traffic = None
         result = {
@@ -271,10 +284,12 @@ def main():
                                    "regression target, exclude mask), float32 outputs" % B,
                        "global_batch": world * B, "ring_batches": a.ring,
                        "launch": ("eager" if graph is None else
-                                  "hipGraph replay" + (", params launch of batch i+1 on a second stream" if a.pipeline else "")),
+                                  "hipGraph replay" + (", params launch of batch i+1 on a second stream" if a.pipeline else "")
+                                  + (", chained (params of batch i+1 ride in the launch of batch i)" if a.chained else "")),
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "epe_vs_oracle_m": epe,
-            "roofline": {"bound": "hbm", "kernel": "scan_params_kernel + scan_preprocess_kernel<float,2>",
+            "roofline": {"bound": "hbm", "kernel": ("scan_preprocess_chain_kernel<float,2,2>" if a.chained
+                                    else "scan_params_kernel + scan_preprocess_kernel<float,2,2>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,

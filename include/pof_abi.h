@@ -108,6 +108,37 @@ int pof_scan_preprocess_phase(const float *ranges, long long sample_stride, int 
                               float *target_reg, float *dyn_mask, float *valid_mask, float *exclude_mask,
                               void *workspace, size_t workspace_bytes, int phases, pof_stream_t stream);
 
+/* Chained form for a stream of batches (a data loader knows the next batch):
+ * ONE launch streams the current batch -- whose workspace must already hold its
+ * params (from the previous chained call, or a phases = 1 call for the first
+ * batch) -- and, on extra workgroups of the same grid, evaluates the params of
+ * the NEXT batch into next->workspace.  The streaming rows are HBM-bound and
+ * leave the ALUs idle, so the next batch's sincos work hides under them and
+ * the steady state is one launch per batch.  next == NULL: plain phases = 2. */
+typedef struct pof_scan_inputs {
+    const double *odom0, *odom1;       /* [B][3], may be NULL when want_flow == 0 */
+    const int32_t *det_offsets;        /* [B+1] or NULL */
+    const double *det_rphi;            /* [D][2] */
+    const uint8_t *det_cls;            /* [D] */
+    int32_t B, D, flow_kind, want_flow;
+    double assoc_radius[3];
+    int32_t labels[3];
+    int32_t pad_;
+    double dyn_radius[3];
+    void *workspace;
+    size_t workspace_bytes;
+} pof_scan_inputs;
+
+int pof_scan_preprocess_chained(const float *ranges, long long sample_stride, int B, int N,
+                                const double *tab, const double *odom0, const double *odom1,
+                                int flow_kind, int canonical, int out_f64, void *xy, void *flow,
+                                const int32_t *det_offsets, const double *det_rphi, const uint8_t *det_cls,
+                                int D, const double *assoc_radius, const int32_t *labels,
+                                const double *dyn_radius, int64_t *closest, int64_t *target_cls,
+                                float *target_reg, float *dyn_mask, float *valid_mask, float *exclude_mask,
+                                void *workspace, size_t workspace_bytes, const pof_scan_inputs *next,
+                                pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A3 on caller-supplied scanner-frame points (the reference's own signature):
  *   get_displacement_from_odometry(scan1_xy, odom0, odom1)   src/utils/utils.py:639-662

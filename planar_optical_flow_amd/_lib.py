@@ -27,6 +27,8 @@ SIGNATURES = {
     "pof_scan_preprocess_workspace_bytes": (_sz, [_i, _i]),
     "pof_scan_preprocess_phase": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                                        _p, _p, _p, _p, _p, _p, _p, _sz, _i, _p]),
+    "pof_scan_preprocess_chained": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
+                                         _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "pof_scan_preprocess": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                                  _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_flow_from_xy": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
@@ -45,6 +47,15 @@ SIGNATURES = {
     "pof_segment_features": (_i, [_p, _p, _i, _i, _d, _i, _p, _p, _p, _p]),
     "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),
 }
+
+
+class ScanInputs(C.Structure):
+    """pof_scan_inputs of include/pof_abi.h."""
+    _fields_ = [("odom0", C.c_void_p), ("odom1", C.c_void_p), ("det_offsets", C.c_void_p),
+                ("det_rphi", C.c_void_p), ("det_cls", C.c_void_p), ("B", C.c_int32), ("D", C.c_int32),
+                ("flow_kind", C.c_int32), ("want_flow", C.c_int32), ("assoc_radius", C.c_double * 3),
+                ("labels", C.c_int32 * 3), ("pad_", C.c_int32), ("dyn_radius", C.c_double * 3),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class PofError(RuntimeError):

@@ -90,7 +90,7 @@ def scan_preprocess_workspace_bytes(B, D):
 def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLOW_DISPLACEMENT,
                     canonical=True, out_dtype=torch.float32, want=("flow",),
                     assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3), dyn_radius=(2.5, 2.0, 2.0),
-                    out=None, workspace=None, phases=3):
+                    out=None, workspace=None, phases=3, next_batch=None):
     """A2-A7 fused, one launch.
 
     scans: [B,T,N] (the last row of each window is the current scan) or [B,N].
@@ -99,6 +99,9 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
     phases: 3 = both launches; 1 = only the per-sample params launch into
           `workspace`, 2 = only the streaming launch (for two-stream pipelining of
           independent batches; B <= 65535 in that mode).
+    next_batch: chained form -- dict(odom0, odom1, dets, workspace) of the NEXT batch; this
+          call then streams the current batch (its params must already be in `workspace`,
+          i.e. phases is forced to 2) and evaluates the next batch's params in the same launch.
     Returns a dict of device tensors.
     """
     scans = _dev(scans, torch.float32, "scans")
@@ -163,6 +166,30 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
         workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     elif workspace.numel() * workspace.element_size() < ws_bytes or not workspace.is_cuda:
         raise ValueError("workspace must be a device tensor of at least %d bytes" % ws_bytes)
+    nxt = None
+    if next_batch is not None:
+        if B > 65535:
+            raise ValueError("chained form needs B <= 65535")
+        nd = next_batch.get("dets")
+        n0, n1 = next_batch.get("odom0"), next_batch.get("odom1")
+        nws = next_batch["workspace"]
+        nxt = _lib.ScanInputs()
+        nxt.want_flow = int("flow" in want)
+        if nxt.want_flow:
+            n0 = _dev(n0, torch.float64, "next odom0")
+            n1 = _dev(n1, torch.float64, "next odom1")
+            nxt.odom0, nxt.odom1, nxt.B = n0.data_ptr(), n1.data_ptr(), n0.shape[0]
+        else:
+            nxt.B = nd.offsets.numel() - 1 if nd is not None else 0
+        if need_det and nd is not None:
+            nxt.det_offsets, nxt.det_rphi, nxt.det_cls = nd.offsets.data_ptr(), nd.rphi.data_ptr(), nd.cls.data_ptr()
+            nxt.D = int(nd.rphi.shape[0])
+        nxt.flow_kind = int(flow_kind)
+        nxt.assoc_radius = (C.c_double * 3)(*assoc_radius)
+        nxt.labels = (C.c_int32 * 3)(*labels)
+        nxt.dyn_radius = (C.c_double * 3)(*dyn_radius)
+        nxt.workspace = nws.data_ptr()
+        nxt.workspace_bytes = nws.numel() * nws.element_size()
     with torch.cuda.device(dev):
         # grid.y carries the sample index: chunk very large batches
         step = 65535
@@ -175,15 +202,16 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
                 return None if t is None else C.c_void_p(t.data_ptr() + s * per * t.element_size())
 
             _lib.call(
-                "pof_scan_preprocess_phase", C.c_void_p(base + 4 * s * stride), stride, n, N, _ptr(tab),
+                "pof_scan_preprocess_chained" if nxt is not None else "pof_scan_preprocess_phase",
+                C.c_void_p(base + 4 * s * stride), stride, n, N, _ptr(tab),
                 sl(odom0, 3) if "flow" in want else None, sl(odom1, 3) if "flow" in want else None,
                 int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
                 sl(xy, 2 * N), sl(flow, 2 * N),
                 sl(dets.offsets, 1) if need_det else None,
                 _ptr(dets.rphi) if need_det else None, _ptr(dets.cls) if need_det else None, D,
                 ar, lb, dr, sl(closest, N), sl(tcls, N), sl(treg, 2 * N), sl(dyn, N), sl(val, N),
-                sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(), int(phases),
-                _stream())
+                sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(),
+                C.byref(nxt) if nxt is not None else int(phases), _stream())
     return out
 
 

@@ -509,3 +509,25 @@ def test_a3c_prepared_flow_and_alignment(ops, geo):
                               out_dtype=torch.float64, want=("flow",))
     want = R.align_next_scan(sb.scans[1, -1], phi, od, scan_dir)
     np.testing.assert_allclose(out["flow"][0].cpu().numpy(), want, rtol=0, atol=1e-12)
+
+
+def test_chained_preprocess_equals_two_launch_form(ops):
+    """pof_scan_preprocess_chained: batch i streamed + params of batch i+1 in one launch."""
+    tab = ops.phi_table()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+    batches = []
+    for seed in (31, 32, 33):
+        sb = synth.make_batch(seed=seed, B=2048, T=2)
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(2048, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        batches.append((T(sb.scans), T(sb.odom0), T(sb.odom1), det, ws))
+    ref = [ops.scan_preprocess(s, tab, o0, o1, d, want=want) for (s, o0, o1, d, _) in batches]
+    s, o0, o1, d, ws = batches[0]
+    ops.scan_preprocess(s, tab, o0, o1, d, want=want, workspace=ws, phases=1)      # prime
+    for i in range(3):
+        s, o0, o1, d, ws = batches[i]
+        ns, n0, n1, nd, nws = batches[(i + 1) % 3]
+        got = ops.scan_preprocess(s, tab, o0, o1, d, want=want, workspace=ws,
+                                  next_batch={"odom0": n0, "odom1": n1, "dets": nd, "workspace": nws})
+        for k in want:
+            assert torch.equal(got[k], ref[i][k]), (i, k)
