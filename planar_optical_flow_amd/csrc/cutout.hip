@@ -35,6 +35,7 @@ struct CutArgs {
     const float *scans;
     int B, T, N, Ns, stride;
     int tile;           // output points per workgroup
+    int span_cap;       // LDSMODE 2: row elements per scan that fit the LDS row buffer
     const double *tab;
     int centered, fixed, P, area_mode;
     float half_width;   // float32(0.5 * window_width)
@@ -74,39 +75,35 @@ __device__ __forceinline__ double frac_index(double a0, double step, double kd, 
     return pof_div_const(ang - phi0, dphi, rdphi);
 }
 
+// s_area[b] = max over the sample's windows of (width > P ? ceil(width / P) : 0).
+// ceil is monotone, so this equals ceil(max width / P) whenever any window exceeds P
+// (what the reference computes) and 0 otherwise.  Grid = (window chunks, B) with an
+// integer atomicMax per workgroup; s_area is zeroed by the launcher.
 __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
 {
-    __shared__ double s_max[kWaves];
-    __shared__ int s_any[kWaves];
-    const int b = blockIdx.x;
+    __shared__ int s_red[kWaves];
+    const int b = blockIdx.y;
     const float *smp = a.scans + (long long)b * a.T * a.N;
     const double phi0 = a.tab[0], dphi = a.tab[1] - a.tab[0], rdphi = 1.0 / dphi;
     const int rowsT = a.fixed ? a.T : 1;  // !fixed: every t has the same window
     const double pm1 = (double)(a.P - 1);
-    double mx = -1.0e300;
-    int any = 0;
-    for (int p = threadIdx.x; p < rowsT * a.Ns; p += kThreads) {
+    int best = 0;
+    const int total = rowsT * a.Ns;
+    for (int p = blockIdx.x * kThreads + threadIdx.x; p < total; p += gridDim.x * kThreads) {
         const int t = a.fixed ? p / a.Ns : a.T - 1;
         const int i = (p % a.Ns) * a.stride;
         Window w = make_window(smp[t * a.N + i], a.tab[i], a.half_width, a.P);
         const double step = (double)w.da;
-        double width = frac_index(w.a0, step, pm1, phi0, dphi, rdphi) - frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
-        mx = fmax(mx, width);
-        any |= width > (double)a.P;
+        const double width = frac_index(w.a0, step, pm1, phi0, dphi, rdphi) - frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
+        if (width > (double)a.P) best = max(best, (int)ceil(width / (double)a.P));
     }
-    mx = wave_max_f64(mx);
-    any = __any(any);
-    if ((threadIdx.x & 63) == 0) {
-        s_max[threadIdx.x >> 6] = mx;
-        s_any[threadIdx.x >> 6] = any;
-    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o, 64));
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = best;
     __syncthreads();
     if (threadIdx.x == 0) {
-        for (int wv = 1; wv < kWaves; ++wv) {
-            mx = fmax(mx, s_max[wv]);
-            any |= s_any[wv];
-        }
-        a.s_area[b] = any ? (int)ceil(mx / (double)a.P) : 0;
+        for (int wv = 1; wv < kWaves; ++wv) best = max(best, s_red[wv]);
+        if (best > 0) atomicMax(&a.s_area[b], best);
     }
 }
 
@@ -132,7 +129,12 @@ struct WinTable {
 __host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 60 + 15) & ~(size_t)15; }
 
 // One workgroup = one sample x `tile` output points.
-//   LDSROWS  the sample's [T][N] rows are staged in LDS as (value, next - value)
+//   LDSMODE  1: the sample's whole [T][N] rows are staged in LDS (parked in registers at
+//               kernel entry, latency hidden behind phase A);
+//            2: rows too large for LDS (N = 3600): after phase A the workgroup reduces
+//               the index range its windows touch and stages only that span of every
+//               row (falls back to L2 gathers when even the span does not fit);
+//            0: gathers straight from global memory
 //   P4       P/4 when it is a compile-time constant (14, 12, 8): the lane ->
 //            (window, k-group) split is then a multiply, and every lane produces
 //            4 consecutive cutout samples -> one float4 store;  0: same with a
@@ -140,7 +142,7 @@ __host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap
 //   FAST     centred output with a power-of-two depth (the configs of the
 //            reference): (ct - d) * (1/depth) without the generic-divisor code
 //   DBG      also write the inds_ct_low debug tensor (tests only)
-template <bool LDSROWS, int P4, bool FAST, bool DBG>
+template <int LDSMODE, int P4, bool FAST, bool DBG>
 __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -156,6 +158,15 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     const double phi0 = a.tab[0], dphi = a.tab[1] - a.tab[0], rdphi = 1.0 / dphi;
     const int s_area = (a.area_mode && a.s_area) ? a.s_area[b] : 0;
     const int PA = s_area * P;
+    constexpr bool LDSROWS = LDSMODE == 1;
+    __shared__ int s_span_lo, s_span_hi;
+    if (LDSMODE == 2) {
+        if (threadIdx.x == 0) {
+            s_span_lo = N;
+            s_span_hi = -1;
+        }
+        __syncthreads();
+    }
 
     // Row loads are issued first and parked in registers; their latency is covered
     // by the arctangents of phase A, and they are written to LDS just before the
@@ -188,7 +199,17 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         wt.hi_clip[p] = (double)(d + a.depth_f32);
         wt.dd[p] = (double)d;
         wt.out_off[p] = a.fixed ? p * P : jj * T * P;   // (jj*T + t)*P, t = 0 when !fixed
-        wt.row_off[p] = a.fixed ? t * N : 0;
+        wt.row_off[p] = a.fixed ? t : 0;                // first scan row this window reads
+        if (LDSMODE == 2) {
+            // index range touched by this window (lerp: floor(idx), +1; area samples stay in
+            // the same angular span; one extra element each side for the float32 step rounding)
+            const double i_first = frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
+            const double i_last = frac_index(w.a0, step, (double)(P - 1), phi0, dphi, rdphi);
+            const int lo_w = min(max((int)floor(i_first) - 1, 0), N - 1);
+            const int hi_w = min(max((int)floor(i_last) + 2, 0), N - 1);
+            atomicMin(&s_span_lo, lo_w);
+            atomicMax(&s_span_hi, hi_w);
+        }
         int isarea = 0;
         double step_a = 0.0;
         if (s_area > 0) {
@@ -212,6 +233,27 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
     }
     __syncthreads();
+    // row addressing: element idx of scan row t lives at rows[(t * rstride) + rbase + idx]
+    int rstride = N, rbase = 0;
+    bool span_lds = false;
+    if (LDSMODE == 2) {
+        const int lo_s = s_span_lo, span = s_span_hi - s_span_lo + 1;
+        span_lds = span > 0 && span <= a.span_cap;
+        if (span_lds) {
+            for (int e = threadIdx.x; e < T * span; e += kThreads) {
+                const int t = e / span, x = e - t * span;
+                s_rows[e] = smp[t * N + lo_s + x];
+            }
+            rstride = span;
+            rbase = -lo_s;
+        }
+        __syncthreads();
+    }
+    auto fetch = [&](int off) -> float {
+        if (LDSMODE == 1) return s_rows[off];
+        if (LDSMODE == 2 && span_lds) return s_rows[off];
+        return smp[off];
+    };
 
     // ---- phase B ----------------------------------------------------------------
     constexpr int KV = (P4 >= 0) ? 4 : 1;
@@ -250,13 +292,13 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                     a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
         }
         for (int tt = 0; tt < tcount; ++tt) {
-            const int roff = row_off + tt * N;
+            const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
                 const int hi = min(lo[u] + 1, N - 1);
-                const float vlo = LDSROWS ? s_rows[roff + lo[u]] : smp[roff + lo[u]];
-                const float vhi = LDSROWS ? s_rows[roff + hi] : smp[roff + hi];
+                const float vlo = fetch(roff + lo[u]);
+                const float vhi = fetch(roff + hi);
                 double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
                 if (isarea) {
                     // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
@@ -267,7 +309,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                         ia = ia < 0.0 ? 0.0 : ia;
                         ia = ia > nm1 ? nm1 : ia;
                         const int ii = (int)rint(ia);
-                        const float v = LDSROWS ? s_rows[roff + ii] : smp[roff + ii];
+                        const float v = fetch(roff + ii);
                         acc = (s == 0) ? v : acc + v;
                     }
                     ct = (double)__fdiv_rn(acc, (float)s_area);
@@ -291,7 +333,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     }
 }
 
-template <bool LDSROWS, bool FAST, bool DBG>
+template <int LDSROWS, bool FAST, bool DBG>
 void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
 {
     if (!vec4) cutout_kernel<LDSROWS, -1, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
@@ -301,7 +343,7 @@ void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool
     else cutout_kernel<LDSROWS, 0, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
 }
 
-template <bool LDSROWS>
+template <int LDSROWS>
 void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
 {
     const bool fast = a.centered && a.depth_pow2;
@@ -345,7 +387,13 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
     a.out = out; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
-        cutout_area_kernel<<<B, kThreads, 0, s>>>(a);
+        if (hipMemsetAsync(workspace, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return POF_E_LAUNCH;
+        const int windows = (fixed ? T : 1) * a.Ns;
+        int chunks = (windows + kThreads - 1) / kThreads;
+        // enough workgroups to fill the chip at small B, at most one window per lane
+        const int want_chunks = (2048 + B - 1) / B;
+        if (chunks > want_chunks) chunks = want_chunks;
+        cutout_area_kernel<<<dim3(chunks, B), kThreads, 0, s>>>(a);
         POF_CHECK_LAUNCH();
     }
     const size_t row_bytes = (size_t)T * N * sizeof(float);
@@ -354,11 +402,16 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
     if (a.tile > a.Ns) a.tile = a.Ns;
     const size_t tbl = win_table_bytes(fixed ? a.tile * T : a.tile);
     const bool rows_in_lds = tbl + row_bytes <= 64 * 1024;
-    const size_t lds = tbl + (rows_in_lds ? row_bytes : 0);
+    // otherwise: per-tile span staging with a 48 KB row buffer
+    a.span_cap = (int)((48 * 1024) / ((size_t)T * sizeof(float)));
+    if (a.span_cap > N) a.span_cap = N;
+    const bool span_mode = !rows_in_lds && a.span_cap >= 64;
+    const size_t lds = tbl + (rows_in_lds ? row_bytes : (span_mode ? (size_t)a.span_cap * T * sizeof(float) : 0));
     dim3 grid((a.Ns + a.tile - 1) / a.tile, B);
     const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
-    if (rows_in_lds) launch_cutout<true>(a, grid, lds, s, vec4);
-    else launch_cutout<false>(a, grid, lds, s, vec4);
+    if (rows_in_lds) launch_cutout<1>(a, grid, lds, s, vec4);
+    else if (span_mode) launch_cutout<2>(a, grid, lds, s, vec4);
+    else launch_cutout<0>(a, grid, lds, s, vec4);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }
