@@ -188,6 +188,16 @@ int pof_cutout(const float *scans, int B, int T, int N, const double *tab, int s
                double padding_val, int area_mode, float *out, int32_t *workspace,
                int32_t *dbg_lo, pof_stream_t stream);
 
+/* Same with a value-path selector: value_mode 0 = float64 value path (bit-exact, what
+ * pof_cutout runs); 1 = float32 value path: the index math stays float64 and exact
+ * (same inds_ct_low / out-of-range / area indices), only lerp, clip and centring run in
+ * float32 (|error| <= 1e-5 in the normalised output).  Compare: the reference's own
+ * scans_to_cutout_torch does its INDEX math in float32 (src/utils/utils.py:337-420). */
+int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, int stride, int centered,
+                  int fixed, double window_width, double window_depth, int num_cutout_pts,
+                  double padding_val, int area_mode, int value_mode, float *out, int32_t *workspace,
+                  int32_t *dbg_lo, pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A11 nms_predicted_center                      src/utils/utils.py:535-571
  * One scan per batch entry.  pred_cls [B][N] float64 scores, pred_reg [B][N][2].

@@ -43,6 +43,8 @@ struct CutArgs {
     double depth;       // window_depth
     double rdepth;      // RN(1/window_depth)
     int depth_pow2;     // 1/window_depth is exact: multiply instead of divide
+    int value_mode;     // 0: float64 value path (bit-exact); 1: float32 value path (exact indices)
+    float padding_f32, rdepth_f32;
     double padding;
     float *out;
     int32_t *s_area;
@@ -139,10 +141,15 @@ __host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap
 //            (window, k-group) split is then a multiply, and every lane produces
 //            4 consecutive cutout samples -> one float4 store;  0: same with a
 //            runtime P/4;  -1: P % 4 != 0, one sample per lane.
-//   FAST     centred output with a power-of-two depth (the configs of the
-//            reference): (ct - d) * (1/depth) without the generic-divisor code
+//   VMODE    0: float64 value path, any depth / centring (bit-exact);
+//            1: same, specialised for centred output with a power-of-two depth (the
+//               reference's configs): (ct - d) * (1/depth);
+//            2: float32 value path -- the index math (angle -> fractional index -> floor,
+//               out-of-range, area indices) stays float64 and exact, only the lerp / clip /
+//               centre arithmetic runs in float32 (|error| <= 1e-5 in the normalised output;
+//               saturated samples are exactly +-1).  Opt-in (value_mode = 1).
 //   DBG      also write the inds_ct_low debug tensor (tests only)
-template <int LDSMODE, int P4, bool FAST, bool DBG>
+template <int LDSMODE, int P4, int VMODE, bool DBG>
 __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -299,7 +306,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 const int hi = min(lo[u] + 1, N - 1);
                 const float vlo = fetch(roff + lo[u]);
                 const float vhi = fetch(roff + hi);
-                double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
+                float mean_a = 0.0f;
                 if (isarea) {
                     // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
                     const double step_a = wt.step_a[p];
@@ -312,19 +319,31 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                         const float v = fetch(roff + ii);
                         acc = (s == 0) ? v : acc + v;
                     }
-                    ct = (double)__fdiv_rn(acc, (float)s_area);
+                    mean_a = __fdiv_rn(acc, (float)s_area);
                 }
-                if (outb[u]) ct = a.padding;
-                // np.clip as compare + select (no NaN canonicalisation needed here)
-                ct = ct < lo_clip ? lo_clip : ct;
-                ct = ct > hi_clip ? hi_clip : ct;
-                if (FAST) {
-                    ct = (ct - dd) * a.rdepth;
-                } else if (a.centered) {
-                    ct = ct - dd;
-                    ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
+                if (VMODE == 2) {
+                    float v = fmaf((float)ratio[u], vhi - vlo, vlo);
+                    if (isarea) v = mean_a;
+                    if (outb[u]) v = a.padding_f32;
+                    const float dlo = (float)lo_clip, dhi = (float)hi_clip, df = (float)dd;  // exact: float32 values
+                    v = fminf(fmaxf(v, dlo), dhi);
+                    if (a.centered) v = a.depth_pow2 ? (v - df) * a.rdepth_f32 : __fdiv_rn(v - df, a.depth_f32);
+                    res[u] = v;
+                } else {
+                    double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
+                    if (isarea) ct = (double)mean_a;
+                    if (outb[u]) ct = a.padding;
+                    // np.clip as compare + select (no NaN canonicalisation needed here)
+                    ct = ct < lo_clip ? lo_clip : ct;
+                    ct = ct > hi_clip ? hi_clip : ct;
+                    if (VMODE == 1) {
+                        ct = (ct - dd) * a.rdepth;
+                    } else if (a.centered) {
+                        ct = ct - dd;
+                        ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
+                    }
+                    res[u] = (float)ct;
                 }
-                res[u] = (float)ct;
             }
             float *dst = out_tile + out_off + tt * P + k0;
             if (KV == 4) *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1 % KV], res[2 % KV], res[3 % KV]);
@@ -333,7 +352,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     }
 }
 
-template <int LDSROWS, bool FAST, bool DBG>
+template <int LDSROWS, int FAST, bool DBG>
 void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
 {
     if (!vec4) cutout_kernel<LDSROWS, -1, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
@@ -349,21 +368,24 @@ void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool 
     const bool fast = a.centered && a.depth_pow2;
     if (a.dbg_lo) {
         // test-only variant, no need to specialise further
-        launch_cutout2<LDSROWS, false, true>(a, grid, lds, s, vec4);
+        launch_cutout2<LDSROWS, 0, true>(a, grid, lds, s, vec4);
+    } else if (a.value_mode == 1) {
+        launch_cutout2<LDSROWS, 2, false>(a, grid, lds, s, vec4);
     } else if (fast) {
-        launch_cutout2<LDSROWS, true, false>(a, grid, lds, s, vec4);
+        launch_cutout2<LDSROWS, 1, false>(a, grid, lds, s, vec4);
     } else {
-        launch_cutout2<LDSROWS, false, false>(a, grid, lds, s, vec4);
+        launch_cutout2<LDSROWS, 0, false>(a, grid, lds, s, vec4);
     }
 }
 
 }  // namespace
 
-extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double *tab, int stride,
-                          int centered, int fixed, double window_width, double window_depth,
-                          int num_cutout_pts, double padding_val, int area_mode, float *out,
-                          int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
+extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, int stride,
+                             int centered, int fixed, double window_width, double window_depth,
+                             int num_cutout_pts, double padding_val, int area_mode, int value_mode,
+                             float *out, int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
 {
+    if (value_mode < 0 || value_mode > 1) return POF_E_BADARG;
     if (!scans || !tab || !out || B < 0 || T < 1 || N < 2 || stride < 1 || num_cutout_pts < 2)
         return POF_E_BADARG;
     if (area_mode && !workspace) return POF_E_WORKSPACE;
@@ -384,6 +406,9 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
         a.depth_pow2 = frexp(window_depth, &e) == 0.5;  // power of two: x/depth == x*(1/depth) exactly
     }
     a.padding = padding_val;
+    a.value_mode = value_mode;
+    a.padding_f32 = (float)padding_val;
+    a.rdepth_f32 = (float)(1.0 / window_depth);
     a.out = out; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
@@ -414,4 +439,13 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
     else launch_cutout<0>(a, grid, lds, s, vec4);
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+
+extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double *tab, int stride,
+                          int centered, int fixed, double window_width, double window_depth,
+                          int num_cutout_pts, double padding_val, int area_mode, float *out,
+                          int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
+{
+    return pof_cutout_ex(scans, B, T, N, tab, stride, centered, fixed, window_width, window_depth, num_cutout_pts,
+                         padding_val, area_mode, 0, out, workspace, dbg_lo, stream);
 }

@@ -286,8 +286,10 @@ def canonical_to_det(ranges, tab, dx, dy):
 
 
 def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, window_depth=1.0,
-           num_cutout_pts=48, padding_val=29.99, area_mode=False, out=None, return_debug=False):
-    """A8 for a batch: scans [B,T,N] float32 -> [B, ceil(N/stride), T, P] float32."""
+           num_cutout_pts=48, padding_val=29.99, area_mode=False, out=None, return_debug=False,
+           exact_values=True):
+    """A8 for a batch: scans [B,T,N] float32 -> [B, ceil(N/stride), T, P] float32.
+    exact_values=False selects the float32 value path (exact indices, values within 1e-5)."""
     scans = _dev(scans, torch.float32, "scans")
     if scans.dim() != 3:
         raise ValueError("scans must be [B,T,N]")
@@ -308,9 +310,9 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
         for s in range(0, B, step):
             n = min(step, B - s)
             ws = torch.empty(max(n, 1), dtype=torch.int32, device=scans.device)
-            _lib.call("pof_cutout", _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
+            _lib.call("pof_cutout_ex", _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
                       int(bool(fixed)), float(window_width), float(window_depth), P, float(padding_val),
-                      int(bool(area_mode)), _ptr(out[s:s + n]), _ptr(ws),
+                      int(bool(area_mode)), 0 if exact_values else 1, _ptr(out[s:s + n]), _ptr(ws),
                       _ptr(dbg[s:s + n]) if dbg is not None else None, _stream())
             if return_debug:
                 dbg_area = ws

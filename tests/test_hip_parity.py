@@ -531,3 +531,19 @@ def test_chained_preprocess_equals_two_launch_form(ops):
                                   next_batch={"odom0": n0, "odom1": n1, "dets": nd, "workspace": nws})
         for k in want:
             assert torch.equal(got[k], ref[i][k]), (i, k)
+
+
+@pytest.mark.parametrize("name", ["dr_spaam", "config_test", "stride2", "near"])
+def test_cutout_float32_value_path(ops, golden, name):
+    """value_mode 1: indices exact (same debug tensor), values within 1e-5 of the exact path."""
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES[name]
+    tab = ops.phi_table(np.radians(inc), n)
+    scans = T(g[name + "_scans"])
+    exact = ops.cutout(scans, tab, **kw)
+    fast = ops.cutout(scans, tab, exact_values=False, **kw)
+    err = (exact - fast).abs().max().item()
+    assert err <= 1e-5, err
+    sat = exact.abs() == 1.0
+    if kw.get("centered", True):
+        assert torch.equal(fast[sat], exact[sat])          # saturated samples are exactly +-1

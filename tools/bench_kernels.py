@@ -26,6 +26,8 @@ if "cutout" in which:
         ms = timeit(lambda: ops.cutout(scans, tab, out=out, **kw))
         byt = B * (T * 450 * 4 + 450 * T * P * 4)
         print("cutout B=%d T=%d fixed=%d P=%d: %.3f ms  %.0f GB/s  %.2f Msamples/s" % (B, T, fixed, P, ms, byt / ms / 1e6, B / ms / 1e3))
+        ms = timeit(lambda: ops.cutout(scans, tab, out=out, exact_values=False, **kw))
+        print("   float32 value path: %.3f ms  %.0f GB/s" % (ms, byt / ms / 1e6))
     # dense 3600-pt geometry (rows do not fit LDS)
     tab2 = ops.phi_table(np.radians(0.1), 3600)
     sb = synth.make_batch(seed=5, B=64, T=11, N=3600, angle_inc=np.radians(0.1))
