@@ -131,11 +131,19 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(sb)
 
+    # test hooks (single-GPU rehearsal of the N > 1 path): POF_BENCH_SHARE_GPU=1 puts every rank
+    # on cuda:0, POF_BENCH_BACKEND=gloo replaces RCCL (which needs one device per rank)
+    if os.environ.get("POF_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("POF_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from planar_optical_flow_amd import ops
 
@@ -238,7 +246,7 @@ def main():
     dt = time.perf_counter() - t0
     dev_ms = ev0.elapsed_time(ev1)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
