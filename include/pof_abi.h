@@ -278,6 +278,30 @@ int pof_rotate_iou(const float *boxes, const float *query, float *iou, int G, in
                    const int32_t *n_valid, const int32_t *k_valid, int criterion, int is_3d,
                    pof_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * N1: device-resident scan store -> batch of windows.
+ *   DROWDataset2.__getitem__ window gather     src/utils/dataset_dr_spaam.py:357-366
+ *   scan <-> odometry time association          src/utils/dataset_dr_spaam.py:370-378
+ * scans_all [S_total][N] float32: all sequences concatenated.  Per sample b:
+ * seq_first[b] = global row of its sequence's first scan, scan_idx[b] = index of the
+ * current scan inside the sequence.  out [B][num_scans+1][N]: rows
+ * max(0, scan_idx - (num_scans+distance-1-j)*stride), j < num_scans, then scan_idx.
+ * row_cur / row_prev [B]: global rows of the current scan and of the last template
+ * row (whose time stamps select odom1 / odom0).
+ * ---------------------------------------------------------------------- */
+int pof_gather_windows(const float *scans_all, const int32_t *seq_first, const int32_t *scan_idx,
+                       int B, int num_scans, int distance, int stride, int N, float *out,
+                       int32_t *row_cur, int32_t *row_prev, pof_stream_t stream);
+
+/* odom{0,1}[b] = odoms[argmin_k |odoms_t[k] - scans_t[row_{prev,cur}[b]]|], k in
+ * [odom_lo[b], odom_hi[b]) (the sample's sequence), float32 differences, first
+ * minimum wins (np.argmin).  odoms [O_total][3] float32 -> odom0/odom1 [B][3] float64;
+ * idx0/idx1 (optional) receive the indices relative to odom_lo. */
+int pof_associate_odometry(const float *scans_t, const float *odoms_t, const float *odoms,
+                           const int32_t *odom_lo, const int32_t *odom_hi, const int32_t *row_cur,
+                           const int32_t *row_prev, int B, double *odom0, double *odom1,
+                           int32_t *idx0, int32_t *idx1, pof_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

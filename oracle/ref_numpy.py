@@ -681,3 +681,47 @@ def rotate_iou(boxes, query_boxes, criterion=-1, is_3d=False):
             for k in range(K):
                 out[i, k] = _iou_pair(query_boxes[k], boxes[i], criterion, is_3d)
     return out
+
+
+# --------------------------------------------------------------------------
+# N1  DROWDataset2.__getitem__ window / odometry indexing
+#     src/utils/dataset_dr_spaam.py:357-378 (+ the static-scene filter :277-290)
+# --------------------------------------------------------------------------
+
+
+def window_indices(scan_idx, num_scans=5, distance=5, scan_stride=1):
+    """Indices (inside the sequence) of the template rows; the current scan is
+    appended by the caller (np.vstack((scans, cur_scan)), :366)."""
+    back = (np.arange(num_scans + distance) * scan_stride)[::-1]
+    return [max(0, scan_idx - int(i)) for i in back[:num_scans]]
+
+
+def associate_odometry(odoms_t, scans_t, scan_idx, scan_inds):
+    """(:370-378) -> (odom0_idx, odom1_idx): float32 |dt| argmin, first minimum."""
+    i1 = int(np.argmin(np.abs(odoms_t - scans_t[scan_idx])))
+    i0 = int(np.argmin(np.abs(odoms_t - scans_t[scan_inds[-1]])))
+    return i0, i1
+
+
+def static_scene_mask(odom):
+    """(:283) keep index i iff odom[i+1] differs from odom[i]; the last one is dropped."""
+    return np.hstack([np.any((odom[1:] - odom[:-1]) != 0.0, axis=1), False])
+
+
+def dataset_item(scans, scans_t, odoms, odoms_t, scan_idx, wcs, was, wps, cutout_kwargs,
+                 num_scans=5, scan_stride=1, pedestrian_only=False, atan_mode="numpy"):
+    """One DROWDataset2.__getitem__ (:339-462) on in-memory sequence arrays."""
+    phi = laser_phi()
+    inds = window_indices(scan_idx, num_scans, 5, scan_stride)
+    cur = scans[scan_idx]
+    win = np.vstack((np.array([scans[i] for i in inds]), cur))
+    i0, i1 = associate_odometry(odoms_t, scans_t, scan_idx, inds)
+    cls, reg = regression_target(cur, phi, wcs, was, wps, pedestrian_only=pedestrian_only)
+    xy = np.array(polar_to_xy(cur, phi)).T
+    flow = flow_to_canonical(displacement_from_odometry(xy, odoms[i0], odoms[i1]), phi)
+    mask = dynamic_mask(xy, wcs, was, wps) * valid_point_mask(cur)
+    out = {"scans": win, "target_cls": cls, "target_reg": reg, "target_flow": flow, "exclude_mask": mask,
+           "odom0": odoms[i0], "odom1": odoms[i1]}
+    if cutout_kwargs is not None:
+        out["input"] = cutout(win, phi, stride=1, atan_mode=atan_mode, **cutout_kwargs)
+    return out

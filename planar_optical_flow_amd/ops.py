@@ -497,3 +497,43 @@ def rotate_iou(boxes, query_boxes, criterion=-1, is_3d=False, n_valid=None, k_va
         _lib.call("pof_rotate_iou", _ptr(b), _ptr(q), _ptr(out), G, N, K, _ptr(n_valid), _ptr(k_valid),
                   int(criterion), int(bool(is_3d)), _stream())
     return out
+
+
+def gather_windows(scans_all, seq_first, scan_idx, num_scans, distance=5, stride=1, out=None):
+    """N1: scans_all [S,N] f32, seq_first / scan_idx [B] int32 -> (windows [B,num_scans+1,N],
+    row_cur [B], row_prev [B])."""
+    scans_all = _dev(scans_all, torch.float32, "scans_all")
+    seq_first = _dev(seq_first, torch.int32, "seq_first")
+    scan_idx = _dev(scan_idx, torch.int32, "scan_idx")
+    B, N = scan_idx.shape[0], scans_all.shape[1]
+    dev = scans_all.device
+    if out is None:
+        out = torch.empty((B, num_scans + 1, N), dtype=torch.float32, device=dev)
+    row_cur = torch.empty(B, dtype=torch.int32, device=dev)
+    row_prev = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        for s in range(0, B, 65535):
+            m = min(65535, B - s)
+            _lib.call("pof_gather_windows", _ptr(scans_all), _ptr(seq_first[s:s + m]), _ptr(scan_idx[s:s + m]), m,
+                      int(num_scans), int(distance), int(stride), N, _ptr(out[s:s + m]), _ptr(row_cur[s:s + m]),
+                      _ptr(row_prev[s:s + m]), _stream())
+    return out, row_cur, row_prev
+
+
+def associate_odometry(scans_t, odoms_t, odoms, odom_lo, odom_hi, row_cur, row_prev):
+    """N1: time association -> (odom0 [B,3] f64, odom1 [B,3] f64, idx0 [B], idx1 [B])."""
+    scans_t = _dev(scans_t, torch.float32, "scans_t")
+    odoms_t = _dev(odoms_t, torch.float32, "odoms_t")
+    odoms = _dev(odoms, torch.float32, "odoms")
+    B = row_cur.shape[0]
+    dev = scans_t.device
+    o0 = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    o1 = torch.empty((B, 3), dtype=torch.float64, device=dev)
+    i0 = torch.empty(B, dtype=torch.int32, device=dev)
+    i1 = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.call("pof_associate_odometry", _ptr(scans_t), _ptr(odoms_t), _ptr(odoms),
+                  _ptr(_dev(odom_lo, torch.int32, "odom_lo")), _ptr(_dev(odom_hi, torch.int32, "odom_hi")),
+                  _ptr(_dev(row_cur, torch.int32, "row_cur")), _ptr(_dev(row_prev, torch.int32, "row_prev")), B,
+                  _ptr(o0), _ptr(o1), _ptr(i0), _ptr(i1), _stream())
+    return o0, o1, i0, i1

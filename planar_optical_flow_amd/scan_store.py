@@ -1,0 +1,95 @@
+"""Device-resident DROW-style data set.
+
+``DROWDataset2`` of the reference (src/utils/dataset_dr_spaam.py:256-471) keeps
+the parsed sequences in host memory and builds one sample per ``__getitem__``
+call in DataLoader workers.  ``DROWDeviceDataset`` holds the same sequences
+concatenated in HBM and produces a whole collated batch with four launches
+(window gather, odometry association, fused preprocess, cutout).
+
+File parsing (csv / .odom2 / json detection files) is out of scope: the
+constructor takes the already-parsed arrays, exactly the tuples the reference's
+``_load_scan_file`` / ``_load_odom`` / ``_load_det_file`` return.  The one-time
+index building of the reference's ``__init__`` (static-scene filter :277-290,
+detection -> scan map :320-334) is restated here on the host with NumPy; it is
+bookkeeping over a few thousand integers, not per-sample compute.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .preprocess import DROWBatchPreprocessor
+
+
+class DROWDeviceDataset:
+    def __init__(self, sequences, num_scans=5, cutout_kwargs=None, pedestrian_only=False, scan_stride=1,
+                 device="cuda", drop_static=True):
+        """sequences: list of dict(scans_ns, scans_t, scans, odoms_t, odoms, dets_ns, dets_wc, dets_wa,
+        dets_wp) with the reference's per-file arrays."""
+        self.num_scans, self.scan_stride, self.distance = num_scans, scan_stride, 5
+        self.device = torch.device(device)
+        self.pre = DROWBatchPreprocessor(cutout_kwargs=cutout_kwargs, pedestrian_only=pedestrian_only,
+                                         device=device)
+        scans, scans_t, odoms, odoms_t = [], [], [], []
+        self._seq_first, self._odom_lo, self._odom_hi = [], [], []
+        self._samples = []  # (sequence, scan index in sequence, wc, wa, wp)
+        row0 = odom0 = 0
+        for seq in sequences:
+            od, od_t = np.asarray(seq["odoms"], np.float32), np.asarray(seq["odoms_t"], np.float32)
+            sc, sc_t = np.asarray(seq["scans"], np.float32), np.asarray(seq["scans_t"], np.float32)
+            sc_ns = np.asarray(seq["scans_ns"])
+            if drop_static:
+                # reference :277-290: keep index i iff odom[i+1] != odom[i]; the same mask is
+                # applied to the scans (the reference assumes one odometry row per scan)
+                keep = np.hstack([np.any((od[1:] - od[:-1]) != 0.0, axis=1), False])
+                if not np.any(keep):
+                    continue
+                od, od_t = od[keep], od_t[keep]
+                sc, sc_t, sc_ns = sc[keep], sc_t[keep], sc_ns[keep]
+            s_idx = len(self._seq_first)
+            self._seq_first.append(row0)
+            self._odom_lo.append(odom0)
+            self._odom_hi.append(odom0 + len(od))
+            scans.append(sc)
+            scans_t.append(sc_t)
+            odoms.append(od)
+            odoms_t.append(od_t)
+            row0 += len(sc)
+            odom0 += len(od)
+            # reference :320-334: annotated frames that survive the filter, in order
+            for d_ns, wc, wa, wp in zip(seq["dets_ns"], seq["dets_wc"], seq["dets_wa"], seq["dets_wp"]):
+                hit = np.where(sc_ns == d_ns)[0]
+                if len(hit) > 0:
+                    self._samples.append((s_idx, int(hit[0]), wc, wa, wp))
+        if not self._samples:
+            raise FileNotFoundError("No valid data")
+        dev = self.device
+        self.scans = torch.from_numpy(np.concatenate(scans)).to(dev)
+        self.scans_t = torch.from_numpy(np.concatenate(scans_t)).to(dev)
+        self.odoms = torch.from_numpy(np.concatenate(odoms)).to(dev)
+        self.odoms_t = torch.from_numpy(np.concatenate(odoms_t)).to(dev)
+
+    def __len__(self):
+        return len(self._samples)
+
+    def get_batch(self, indices):
+        """The collated batch dict of ``collate_batch([ds[i] for i in indices])``: device tensors for the
+        tensor keys (scans, input, target_cls, target_reg, target_flow, exclude_mask), python lists for
+        the annotation keys."""
+        smp = [self._samples[i] for i in indices]
+        dev = self.device
+        seq = np.array([s[0] for s in smp])
+        seq_first = torch.from_numpy(np.asarray(self._seq_first, np.int32)[seq]).to(dev)
+        odom_lo = torch.from_numpy(np.asarray(self._odom_lo, np.int32)[seq]).to(dev)
+        odom_hi = torch.from_numpy(np.asarray(self._odom_hi, np.int32)[seq]).to(dev)
+        scan_idx = torch.from_numpy(np.array([s[1] for s in smp], np.int32)).to(dev)
+        windows, row_cur, row_prev = ops.gather_windows(self.scans, seq_first, scan_idx, self.num_scans,
+                                                        self.distance, self.scan_stride)
+        odom0, odom1, _, idx1 = ops.associate_odometry(self.scans_t, self.odoms_t, self.odoms, odom_lo, odom_hi,
+                                                       row_cur, row_prev)
+        dets = self.pre.make_detections([s[2] for s in smp], [s[3] for s in smp], [s[4] for s in smp])
+        batch = self.pre(windows, odom0, odom1, dets)
+        batch["odom0"] = odom0
+        batch["dets_wc"] = [s[2] for s in smp]
+        batch["dets_wa"] = [s[3] for s in smp]
+        batch["dets_wp"] = [s[4] for s in smp]
+        return batch

@@ -183,3 +183,49 @@ def test_box_regressor_dropin(golden):
         direct = br.model(x)[0].cpu().numpy()
     np.testing.assert_allclose(out[2:4], direct[:2], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(out[4], direct[2] + 0.3, rtol=1e-4, atol=1e-5)
+
+
+def test_device_dataset_equals_reference_getitem(golden):
+    """N1: the reference's DROWDataset2.__getitem__ + collate_batch (golden, produced by the
+    reference itself) vs the device-resident data set: four launches for the whole batch."""
+    from dataset_fixture import CUTOUT_KW, load_sequences
+    from planar_optical_flow_amd.scan_store import DROWDeviceDataset
+    g = golden("dataset_items")
+    seqs = load_sequences(g)
+    ds = DROWDeviceDataset(seqs, num_scans=5, cutout_kwargs=CUTOUT_KW, drop_static=False)
+    n = int(g["n_items"])
+    assert len(ds) == n
+    batch = ds.get_batch(list(range(n)))
+    assert torch.equal(batch["scans"].cpu(), torch.from_numpy(g["out_scans"]))            # window gather
+    assert np.array_equal(batch["odom1"].cpu().numpy().astype(np.float32), g["out_odom1"])  # time association
+    assert np.array_equal(batch["target_cls"].cpu().numpy(), g["out_target_cls"])
+    np.testing.assert_allclose(batch["target_reg"].cpu().numpy(), g["out_target_reg"], atol=1e-6)
+    np.testing.assert_allclose(batch["target_flow"].cpu().numpy(), g["out_target_flow"], atol=5e-6)
+    assert np.array_equal(batch["exclude_mask"].cpu().numpy().astype(np.float64), g["out_exclude_mask"])
+    got = batch["input"][:3].cpu().numpy()
+    frac = np.mean(np.abs(got - g["out_input_first3"]) > 1e-4)      # np.arctan last-bit effect only
+    assert frac < 2e-3, frac
+    phi = R.laser_phi()
+    assert np.array_equal(got[0], R.cutout(g["out_scans"][0], phi, atan_mode="cr", **CUTOUT_KW))
+    # a shuffled subset gives the same rows
+    sub = ds.get_batch([5, 0, n - 1])
+    assert torch.equal(sub["scans"], batch["scans"][[5, 0, n - 1]])
+    assert torch.equal(sub["target_cls"], batch["target_cls"][[5, 0, n - 1]])
+
+
+def test_device_dataset_static_filter():
+    from planar_optical_flow_amd.scan_store import DROWDeviceDataset
+    rng = np.random.default_rng(9)
+    S = 20
+    sb = synth.make_batch(seed=55, B=S, T=1)
+    od = np.cumsum(rng.uniform(-0.02, 0.02, (S, 3)), axis=0).astype(np.float32)
+    od[5:9] = od[5]                                   # a static stretch
+    seq = {"scans": sb.scans[:, 0], "scans_ns": np.arange(S), "scans_t": np.arange(S, dtype=np.float32),
+           "odoms_t": np.arange(S, dtype=np.float32), "odoms": od, "dets_ns": np.arange(0, S, 2),
+           "dets_wc": [[] for _ in range(10)], "dets_wa": [[] for _ in range(10)],
+           "dets_wp": [[[2.0, 0.1]] for _ in range(10)]}
+    ds = DROWDeviceDataset([seq], cutout_kwargs=None)
+    keep = R.static_scene_mask(od)
+    assert ds.scans.shape[0] == int(keep.sum())
+    kept_ns = np.arange(S)[keep]
+    assert len(ds) == sum(1 for d in range(0, S, 2) if d in kept_ns)

@@ -177,3 +177,28 @@ def test_a13_fits_against_lapack():
     reg = linear_model.LinearRegression().fit(seg[:, 0].reshape(-1, 1), seg[:, 1].reshape(-1, 1))
     k, b, _ = R.fit_line(seg)
     np.testing.assert_allclose([k, b], [reg.coef_[0, 0], reg.intercept_[0]], rtol=1e-9)
+
+
+def test_n1_dataset_getitem(golden):
+    """Oracle restatement of DROWDataset2.__getitem__ == the reference's own __getitem__ +
+    collate_batch on the same in-memory sequences (window gather, odometry association,
+    targets, masks, cutout)."""
+    from dataset_fixture import CUTOUT_KW, flat_samples, load_sequences
+    g = golden("dataset_items")
+    seqs = load_sequences(g)
+    samples = flat_samples(seqs)
+    assert len(samples) == int(g["n_items"])
+    for i, (q, si, wc, wa, wp) in enumerate(samples):
+        s = seqs[q]
+        it = R.dataset_item(s["scans"], s["scans_t"], s["odoms"], s["odoms_t"], si, wc, wa, wp,
+                            CUTOUT_KW if i < 3 else None)
+        assert np.array_equal(it["scans"], g["out_scans"][i])
+        assert np.array_equal(it["target_cls"], g["out_target_cls"][i])
+        assert np.array_equal(it["target_reg"], g["out_target_reg"][i])
+        np.testing.assert_allclose(it["target_flow"], g["out_target_flow"][i], rtol=1e-12, atol=1e-15)
+        assert np.array_equal(it["exclude_mask"], g["out_exclude_mask"][i])
+        assert np.array_equal(it["odom1"], g["out_odom1"][i])
+        if i < 3:
+            assert np.array_equal(it["input"], g["out_input_first3"][i])
+    # the window really clamps at the sequence start for early scans
+    assert R.window_indices(3) == [0, 0, 0, 0, 0] and R.window_indices(12) == [3, 4, 5, 6, 7]

@@ -256,6 +256,55 @@ def main():
         gb["abs_sum_" + tag] = np.array([float(v.abs().sum()) for v in mref.state_dict().values()])
     np.savez_compressed(os.path.join(OUT, "box_head.npz"), **gb)
 
+    # ---------------- N1: the reference's own Dataset.__getitem__ + collate_batch ----------
+    # DROWDataset2 is driven with in-memory synthetic sequences (its __init__ only parses
+    # files); every sample then goes through the reference's real __getitem__.
+    rng = np.random.default_rng(71)
+    ds2 = DROWDataset2.__new__(DROWDataset2)
+    ds2._num_scans, ds2._use_data_augmentation = 5, False
+    ds2._cutout_kwargs = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+                              padding_val=29.99, area_mode=True)
+    ds2._network_type, ds2._polar_grid_kwargs, ds2._pedestrian_only = "cutout", None, False
+    ds2._scan_stride, ds2._pt_stride, ds2.max_scan_dist = 1, 1, 6
+    ds2.seq_names, ds2.scans, ds2.scans_ns, ds2.scans_t = [], [], [], []
+    ds2.odoms_t, ds2.odoms, ds2.dets_ns, ds2.dets_wc, ds2.dets_wa, ds2.dets_wp = [], [], [], [], [], []
+    ds2.idet2iscan, ds2.flat_seq_inds, ds2.flat_det_inds = [], [], []
+    gd = {}
+    for q, (S, every) in enumerate(((34, 3), (27, 4))):
+        sbq = synth.make_batch(seed=300 + q, B=S, T=1)
+        sc = sbq.scans[:, 0]
+        ns = np.arange(500 * (q + 1), 500 * (q + 1) + S, dtype=np.uint32)
+        st = (np.arange(S) * 0.08 + 3.0 + 0.013 * q).astype(np.float32)
+        O = 2 * S + 3
+        ot = (np.arange(O) * 0.04 + 2.97).astype(np.float32)
+        od = np.cumsum(rng.uniform(-0.02, 0.02, (O, 3)), axis=0).astype(np.float32)
+        dns = ns[::every]
+        wcs, was, wps = [], [], []
+        for _ in dns:
+            k = rng.integers(0, 4, 3)
+            mk = lambda n: [[float(rng.uniform(1, 8)), float(rng.uniform(-1.6, 1.6))] for _ in range(n)]
+            wcs.append(mk(k[0])); was.append(mk(k[1])); wps.append(mk(k[2]))
+        ds2.seq_names.append("seq%d" % q); ds2.scans.append(sc); ds2.scans_ns.append(ns); ds2.scans_t.append(st)
+        ds2.odoms_t.append(ot); ds2.odoms.append(od); ds2.dets_ns.append(dns)
+        ds2.dets_wc.append(wcs); ds2.dets_wa.append(was); ds2.dets_wp.append(wps)
+        m = {i: int(np.where(ns == d)[0][0]) for i, d in enumerate(dns)}
+        ds2.idet2iscan.append(m)
+        ds2.flat_seq_inds += [q] * len(m)
+        ds2.flat_det_inds += list(range(len(m)))
+        gd.update({"scans%d" % q: sc, "scans_ns%d" % q: ns, "scans_t%d" % q: st, "odoms_t%d" % q: ot,
+                   "odoms%d" % q: od, "dets_ns%d" % q: dns})
+        for nm, lst in (("wc", wcs), ("wa", was), ("wp", wps)):
+            gd["%s_cnt%d" % (nm, q)] = np.array([len(x) for x in lst], dtype=np.int32)
+            gd["%s_val%d" % (nm, q)] = np.array([v for x in lst for v in x], dtype=np.float64).reshape(-1, 2)
+    items = [ds2[i] for i in range(len(ds2))]
+    coll = ds2.collate_batch(items)
+    gd["n_items"] = len(items)
+    for k in ("scans", "target_cls", "target_reg", "target_flow", "exclude_mask"):
+        gd["out_" + k] = coll[k]
+    gd["out_odom1"] = np.array(coll["odom1"])
+    gd["out_input_first3"] = coll["input"][:3]
+    np.savez_compressed(os.path.join(OUT, "dataset_items.npz"), **gd)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
