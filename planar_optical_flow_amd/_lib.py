@@ -77,6 +77,11 @@ def load(path=None):
     if _lib is not None and path is None:
         return _lib
     path = path or LIB_PATH
+    # torch must be imported BEFORE the library is dlopen'ed: PyTorch-ROCm ships its own
+    # libamdhip64, and the process has to end up with ONE HIP runtime -- the one that owns
+    # torch's devices and streams.  Loaded the other way round, libpof_hip.so binds to the
+    # system runtime and every launch on a torch stream fails (hipErrorInvalidResourceHandle).
+    import torch  # noqa: F401
     if not os.path.exists(path):
         raise ImportError(
             "libpof_hip.so not found at %s -- build it with "

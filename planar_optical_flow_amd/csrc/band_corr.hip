@@ -167,6 +167,7 @@ int launch_k(const float *f1, const float *f2, float *out, int B, int C, int n, 
 extern "C" int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C,
                                     int n, int kernel_size, int max_disp, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!feat1 || !feat2 || !out || B < 0 || C < 1 || n < 1) return POF_E_BADARG;
     if (kernel_size < 1 || kernel_size > kMaxK || (kernel_size & 1) == 0) return POF_E_SHAPE;
     if (max_disp < 0 || 2 * max_disp + 1 > kMaxD) return POF_E_SHAPE;
@@ -189,6 +190,7 @@ extern "C" int pof_band_correlation_backward(const float *feat1, const float *fe
                                              float *d_feat1, float *d_feat2, int B, int C, int n,
                                              int kernel_size, int max_disp, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!feat1 || !feat2 || !g_out || !d_feat1 || !d_feat2 || B < 0 || C < 1 || n < 1) return POF_E_BADARG;
     if (kernel_size < 1 || kernel_size > kMaxK || (kernel_size & 1) == 0) return POF_E_SHAPE;
     if (max_disp < 0 || 2 * max_disp + 1 > kMaxD) return POF_E_SHAPE;

@@ -385,6 +385,7 @@ extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const doub
                              int num_cutout_pts, double padding_val, int area_mode, int value_mode,
                              float *out, int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (value_mode < 0 || value_mode > 1) return POF_E_BADARG;
     if (!scans || !tab || !out || B < 0 || T < 1 || N < 2 || stride < 1 || num_cutout_pts < 2)
         return POF_E_BADARG;
@@ -446,6 +447,7 @@ extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double 
                           int num_cutout_pts, double padding_val, int area_mode, float *out,
                           int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     return pof_cutout_ex(scans, B, T, N, tab, stride, centered, fixed, window_width, window_depth, num_cutout_pts,
                          padding_val, area_mode, 0, out, workspace, dbg_lo, stream);
 }

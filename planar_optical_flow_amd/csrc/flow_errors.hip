@@ -54,6 +54,7 @@ __global__ __launch_bounds__(kThreads) void flow_errors_kernel(const float *pred
 extern "C" int pof_flow_errors(const float *pred, const float *target, const float *mask, int B, int N,
                                double *epe_sum, double *aae_sum, double *cnt, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!pred || !target || B < 0 || N < 1) return POF_E_BADARG;
     if (B == 0) return POF_OK;
     flow_errors_kernel<<<B, kThreads, 0, pof_stream(stream)>>>(pred, target, mask, N, epe_sum, aae_sum, cnt);

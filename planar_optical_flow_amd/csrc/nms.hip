@@ -164,6 +164,7 @@ extern "C" int pof_nms_predicted_center(const float *ranges, const double *tab, 
                                         int32_t *instance_mask, void *workspace, size_t workspace_bytes,
                                         pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     (void)workspace;
     (void)workspace_bytes;
     if (!ranges || !tab || !pred_cls || !pred_reg || !det_xy || !det_cls || !num_det || !instance_mask)

@@ -7,6 +7,11 @@
 
 #define POF_WAVE 64
 
+// hipGetLastError() reports (and clears) the last error of ANY earlier HIP call of this
+// thread -- e.g. a benign one inside the caller's framework.  Every entry point therefore
+// drops stale state first, so that POF_CHECK_LAUNCH() only sees its own launches.
+#define POF_CLEAR_STALE_ERROR() (void)hipGetLastError()
+
 #define POF_CHECK_LAUNCH()                                   \
     do {                                                     \
         if (hipGetLastError() != hipSuccess) return POF_E_LAUNCH; \

@@ -201,6 +201,7 @@ extern "C" int pof_rotate_iou(const float *boxes, const float *query, float *iou
                               const int32_t *n_valid, const int32_t *k_valid, int criterion, int is_3d,
                               pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!boxes || !query || !iou || G < 0 || N < 0 || K < 0) return POF_E_BADARG;
     if (criterion < -1) return POF_E_BADARG;
     if (G == 0 || N == 0 || K == 0) return POF_OK;

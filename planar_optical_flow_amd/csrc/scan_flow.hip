@@ -669,6 +669,7 @@ extern "C" int pof_flow_from_xy(const double *xy, const double *odom0, const dou
                                 int canonical, const double *tab, double *flow, int B, int N,
                                 pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!xy || !odom0 || !odom1 || !flow || B < 0 || N < 1) return POF_E_BADARG;
     if (flow_kind < 0 || flow_kind > 4) return POF_E_BADARG;
     if (canonical && !tab) return POF_E_BADARG;
@@ -681,6 +682,7 @@ extern "C" int pof_flow_from_xy(const double *xy, const double *odom0, const dou
 extern "C" int pof_xy_to_rphi(const double *x, const double *y, double *r, double *phi, long long n,
                               pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!x || !y || !r || !phi || n < 0) return POF_E_BADARG;
     if (n == 0) return POF_OK;
     xy_to_rphi_kernel<<<(unsigned)((n + 255) / 256), 256, 0, pof_stream(stream)>>>(x, y, r, phi, n);
@@ -690,6 +692,7 @@ extern "C" int pof_xy_to_rphi(const double *x, const double *y, double *r, doubl
 
 extern "C" int pof_laser_phi(double angle_inc, int num_pts, double *tab, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!tab || num_pts < 2) return POF_E_BADARG;
     // host scalar arithmetic, identical to the Python float arithmetic of the reference
     const double fov = (double)(num_pts - 1) * angle_inc;
@@ -862,6 +865,7 @@ extern "C" int pof_scan_preprocess_phase(const float *ranges, long long sample_s
                                          float *valid_mask, float *exclude_mask, void *workspace,
                                          size_t workspace_bytes, int phases, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     return launch_preprocess(ranges, sample_stride, B, N, tab, odom0, odom1, flow_kind, canonical, out_f64, xy, flow,
                              det_offsets, det_rphi, det_cls, D, assoc_radius, labels, dyn_radius, closest,
                              target_cls, target_reg, dyn_mask, valid_mask, exclude_mask, workspace,
@@ -879,6 +883,7 @@ extern "C" int pof_scan_preprocess_chained(const float *ranges, long long sample
                                            size_t workspace_bytes, const pof_scan_inputs *next,
                                            pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     return launch_preprocess(ranges, sample_stride, B, N, tab, odom0, odom1, flow_kind, canonical, out_f64, xy, flow,
                              det_offsets, det_rphi, det_cls, D, assoc_radius, labels, dyn_radius, closest,
                              target_cls, target_reg, dyn_mask, valid_mask, exclude_mask, workspace,
@@ -895,6 +900,7 @@ extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride,
                                    float *valid_mask, float *exclude_mask, void *workspace,
                                    size_t workspace_bytes, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     return pof_scan_preprocess_phase(ranges, sample_stride, B, N, tab, odom0, odom1, flow_kind, canonical, out_f64,
                                      xy, flow, det_offsets, det_rphi, det_cls, D, assoc_radius, labels, dyn_radius,
                                      closest, target_cls, target_reg, dyn_mask, valid_mask, exclude_mask, workspace,
@@ -904,6 +910,7 @@ extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride,
 extern "C" int pof_rotate_flow(const void *flow_in, void *flow_out, const double *tab, int B, int N,
                                int to_canonical, int is_f64, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!flow_in || !flow_out || !tab || B < 0 || N < 1) return POF_E_BADARG;
     long long total = (long long)B * N;
     if (total == 0) return POF_OK;
@@ -922,6 +929,7 @@ extern "C" int pof_det_to_canonical(const float *ranges, const double *tab, cons
                                     const double *det_phi, double *dx, double *dy, int B, int N,
                                     pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!ranges || !tab || !det_r || !det_phi || !dx || !dy || B < 0 || N < 1) return POF_E_BADARG;
     long long total = (long long)B * N;
     if (total == 0) return POF_OK;
@@ -935,6 +943,7 @@ extern "C" int pof_canonical_to_det(const float *ranges, const double *tab, cons
                                     const double *dy, double *det_r, double *det_phi, int B, int N,
                                     pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!ranges || !tab || !det_r || !det_phi || !dx || !dy || B < 0 || N < 1) return POF_E_BADARG;
     long long total = (long long)B * N;
     if (total == 0) return POF_OK;

@@ -98,6 +98,7 @@ extern "C" int pof_gather_windows(const float *scans_all, const int32_t *seq_fir
                                   int B, int num_scans, int distance, int stride, int N, float *out,
                                   int32_t *row_cur, int32_t *row_prev, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!scans_all || !seq_first || !scan_idx || !out || !row_cur || !row_prev) return POF_E_BADARG;
     if (B < 0 || num_scans < 1 || distance < 0 || stride < 1 || N < 1) return POF_E_BADARG;
     if (B == 0) return POF_OK;
@@ -113,6 +114,7 @@ extern "C" int pof_associate_odometry(const float *scans_t, const float *odoms_t
                                       const int32_t *row_prev, int B, double *odom0, double *odom1,
                                       int32_t *idx0, int32_t *idx1, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!scans_t || !odoms_t || !odoms || !odom_lo || !odom_hi || !row_cur || !row_prev || !odom0 || !odom1)
         return POF_E_BADARG;
     if (B < 0) return POF_E_BADARG;

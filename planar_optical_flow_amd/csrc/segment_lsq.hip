@@ -179,6 +179,7 @@ extern "C" int pof_segment_features(const float *ranges, const double *tab, int 
                                     double jump_dist, int max_seg, int32_t *seg_id, int32_t *num_seg,
                                     double *feat, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!ranges || !tab || !seg_id || !num_seg || !feat || B < 0 || N < 1 || max_seg < 1)
         return POF_E_BADARG;
     if (B == 0) return POF_OK;

@@ -241,6 +241,7 @@ extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, con
                                      double alpha, float *band, float *prob, float *out,
                                      pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!emb_x || !emb_t || !x || !tmpl || !prob || !out) return POF_E_BADARG;
     if (B < 0 || N < 1 || E < 1 || F < 1) return POF_E_BADARG;
     // the reference uses hw = int(window/2) neighbours each side: an even window
@@ -265,6 +266,7 @@ extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *e
                                               float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
                                               float *d_tmpl, pof_stream_t stream)
 {
+    POF_CLEAR_STALE_ERROR();
     if (!emb_x || !emb_t || !tmpl || !prob || !g_out || !dsim || !d_emb_x || !d_emb_t || !d_x || !d_tmpl)
         return POF_E_BADARG;
     if (B < 0 || N < 1 || E < 1 || F < 1) return POF_E_BADARG;
