@@ -22,6 +22,8 @@
 //               outputs, the range rows sit in LDS (loaded into registers at
 //               kernel entry, their latency hidden behind phase A), floor/ratio
 //               use trunc + v_fract (exact in range), np.clip is compare + select.
+#include <type_traits>
+
 #include "pof_common.h"
 
 namespace {
@@ -73,7 +75,9 @@ __device__ __forceinline__ Window make_window(float d, double phi_i, float half_
 __device__ __forceinline__ double frac_index(double a0, double step, double kd, double phi0,
                                              double dphi, double rdphi)
 {
-    double ang = a0 + kd * step;
+    // k*step is exact in float64 (k < 2^12, step has a 24-bit significand), so the reference's
+    // RN(a0 + RN(k*step)) is one fused multiply-add
+    const double ang = fma(kd, step, a0);
     return pof_div_const(ang - phi0, dphi, rdphi);
 }
 
@@ -112,23 +116,41 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
 // LDS window table: structure of arrays with `cap` entries each, carved from
 // dynamic LDS (cap = tile*T when `fixed`, tile otherwise; <= kMaxWin).
 struct WinTable {
-    double *a0, *step, *lo_clip, *hi_clip, *dd, *step_a;
-    int *isarea, *out_off, *row_off;
+    double *a0, *step, *dd, *step_a;
+    float *ylo, *yhi, *ypad;      // output-space clip bounds and the padded output value
+    int *isarea, *out_off, *row_off, *alist;
     __device__ WinTable(unsigned char *base, int cap)
     {
         a0 = reinterpret_cast<double *>(base);
         step = a0 + cap;
-        lo_clip = step + cap;
-        hi_clip = lo_clip + cap;
-        dd = hi_clip + cap;
+        dd = step + cap;
         step_a = dd + cap;
-        isarea = reinterpret_cast<int *>(step_a + cap);
+        ylo = reinterpret_cast<float *>(step_a + cap);
+        yhi = ylo + cap;
+        ypad = yhi + cap;
+        isarea = reinterpret_cast<int *>(ypad + cap);
         out_off = isarea + cap;
         row_off = out_off + cap;
+        alist = row_off + cap;
     }
 };
-// bytes per entry (6 doubles + 3 ints), rounded so the rows that follow stay 16-byte aligned
+// bytes per entry (4 doubles + 3 floats + 4 ints), rounded so the rows that follow stay 16-byte aligned
 __host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 60 + 15) & ~(size_t)15; }
+
+// The tail of the reference's arithmetic, ct -> output: optional centring and scaling in
+// float64, then the float32 cast.  It is monotone in ct, so np.clip(ct, lo, hi) before it
+// equals a float32 clamp after it with the bounds pushed through the same function --
+// which turns two float64 compare/selects per sample into one v_med3_f32.
+template <int VMODE>
+__device__ __forceinline__ float finish_value(const CutArgs &a, double ct, double dd)
+{
+    if (VMODE == 1) return (float)((ct - dd) * a.rdepth);
+    if (a.centered) {
+        ct = ct - dd;
+        ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
+    }
+    return (float)ct;
+}
 
 // One workgroup = one sample x `tile` output points.
 //   LDSMODE  1: the sample's whole [T][N] rows are staged in LDS (parked in registers at
@@ -166,14 +188,13 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     const int s_area = (a.area_mode && a.s_area) ? a.s_area[b] : 0;
     const int PA = s_area * P;
     constexpr bool LDSROWS = LDSMODE == 1;
-    __shared__ int s_span_lo, s_span_hi;
-    if (LDSMODE == 2) {
-        if (threadIdx.x == 0) {
-            s_span_lo = N;
-            s_span_hi = -1;
-        }
-        __syncthreads();
+    __shared__ int s_span_lo, s_span_hi, s_acount;
+    if (threadIdx.x == 0) {
+        s_span_lo = N;
+        s_span_hi = -1;
+        s_acount = 0;
     }
+    __syncthreads();
 
     // Row loads are issued first and parked in registers; their latency is covered
     // by the arctangents of phase A, and they are written to LDS just before the
@@ -202,9 +223,17 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         const double step = (double)w.da;
         wt.a0[p] = w.a0;
         wt.step[p] = step;
-        wt.lo_clip[p] = (double)(d - a.depth_f32);
-        wt.hi_clip[p] = (double)(d + a.depth_f32);
-        wt.dd[p] = (double)d;
+        {
+            // clip bounds are float32 in the reference (dists -/+ window_depth on a float32 array)
+            const double lo_c = (double)(d - a.depth_f32), hi_c = (double)(d + a.depth_f32), dd_ = (double)d;
+            constexpr int VT = (VMODE == 1) ? 1 : 0;   // the exact tail also defines the bounds of VMODE 2
+            const float ylo = finish_value<VT>(a, lo_c, dd_), yhi = finish_value<VT>(a, hi_c, dd_);
+            const double padc = fmin(fmax(a.padding, lo_c), hi_c);
+            wt.ylo[p] = ylo;
+            wt.yhi[p] = yhi;
+            wt.ypad[p] = finish_value<VT>(a, padc, dd_);
+            wt.dd[p] = dd_;
+        }
         wt.out_off[p] = a.fixed ? p * P : jj * T * P;   // (jj*T + t)*P, t = 0 when !fixed
         wt.row_off[p] = a.fixed ? t : 0;                // first scan row this window reads
         if (LDSMODE == 2) {
@@ -227,6 +256,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
         wt.isarea[p] = isarea;
         wt.step_a[p] = step_a;
+        if (isarea) wt.alist[atomicAdd(&s_acount, 1)] = p;
     }
     if (LDSROWS) {
         if (vec_stage) {
@@ -270,26 +300,28 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     float *out_tile = a.out + ((long long)b * a.Ns + j0) * T * P;
     const int tcount = a.fixed ? 1 : T;
 
-    for (int g = threadIdx.x; g < total; g += kThreads) {
-        const int p = (P4 > 0) ? g / P4 : g / per_win;
-        const int k0 = (g - p * per_win) * KV;
+    // One (window, 4-sample group): AREA = false is the interpolation path, AREA = true the
+    // area-sampling path of windows that cover more than P raw points.  Two instantiations
+    // keep every area-only instruction (and its selects) out of the common loop.
+    auto group = [&](auto area_tag, const int p, const int k0) {
+        constexpr bool AREA = decltype(area_tag)::value;
         const double a0 = wt.a0[p], step = wt.step[p];
-        const double lo_clip = wt.lo_clip[p], hi_clip = wt.hi_clip[p], dd = wt.dd[p];
-        const bool isarea = wt.isarea[p] != 0;
+        const double dd = wt.dd[p];
+        const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
         const double kd0 = (double)k0;
-        double idx[KV], ratio[KV];
+        double ratio[KV];
         int lo[KV];
         bool outb[KV];
 #pragma unroll
         for (int u = 0; u < KV; ++u) {
-            idx[u] = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
+            const double idx = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
             // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
-            outb[u] = (__double2hiint(idx[u]) < 0) || (idx[u] > nm1);
+            outb[u] = (__double2hiint(idx) < 0) || (idx > nm1);
             // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
             // range the value is replaced by the padding, only the address must stay legal
-            lo[u] = min(max((int)idx[u], 0), N - 1);
-            ratio[u] = __builtin_amdgcn_fract(idx[u]);
+            lo[u] = min(max((int)idx, 0), N - 1);
+            ratio[u] = __builtin_amdgcn_fract(idx);
         }
         if (DBG) {
             const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
@@ -298,57 +330,65 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 for (int u = 0; u < KV; ++u)
                     a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
         }
+        const double step_a = AREA ? wt.step_a[p] : 0.0;
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
-                const int hi = min(lo[u] + 1, N - 1);
-                const float vlo = fetch(roff + lo[u]);
-                const float vhi = fetch(roff + hi);
-                float mean_a = 0.0f;
-                if (isarea) {
-                    // area sampling: mean of s_area nearest-neighbour samples (float32 sum, in order)
-                    const double step_a = wt.step_a[p];
+                float y;
+                if (AREA) {
+                    // mean of s_area nearest-neighbour samples: float32 sum in order, float32 divide
                     float acc = 0.0f;
                     for (int s = 0; s < s_area; ++s) {
                         double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
                         ia = ia < 0.0 ? 0.0 : ia;
                         ia = ia > nm1 ? nm1 : ia;
-                        const int ii = (int)rint(ia);
-                        const float v = fetch(roff + ii);
+                        const float v = fetch(roff + (int)rint(ia));
                         acc = (s == 0) ? v : acc + v;
                     }
-                    mean_a = __fdiv_rn(acc, (float)s_area);
-                }
-                if (VMODE == 2) {
-                    float v = fmaf((float)ratio[u], vhi - vlo, vlo);
-                    if (isarea) v = mean_a;
-                    if (outb[u]) v = a.padding_f32;
-                    const float dlo = (float)lo_clip, dhi = (float)hi_clip, df = (float)dd;  // exact: float32 values
-                    v = fminf(fmaxf(v, dlo), dhi);
-                    if (a.centered) v = a.depth_pow2 ? (v - df) * a.rdepth_f32 : __fdiv_rn(v - df, a.depth_f32);
-                    res[u] = v;
-                } else {
-                    double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
-                    if (isarea) ct = (double)mean_a;
-                    if (outb[u]) ct = a.padding;
-                    // np.clip as compare + select (no NaN canonicalisation needed here)
-                    ct = ct < lo_clip ? lo_clip : ct;
-                    ct = ct > hi_clip ? hi_clip : ct;
-                    if (VMODE == 1) {
-                        ct = (ct - dd) * a.rdepth;
-                    } else if (a.centered) {
-                        ct = ct - dd;
-                        ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
+                    const float mean_a = __fdiv_rn(acc, (float)s_area);
+                    if (VMODE == 2) {
+                        const float df = (float)dd;
+                        y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
+                                       : mean_a;
+                    } else {
+                        y = finish_value<VMODE>(a, (double)mean_a, dd);
                     }
-                    res[u] = (float)ct;
+                } else {
+                    const float vlo = fetch(roff + lo[u]);
+                    const float vhi = fetch(roff + min(lo[u] + 1, N - 1));
+                    if (VMODE == 2) {
+                        float v = fmaf((float)ratio[u], vhi - vlo, vlo);
+                        const float df = (float)dd;  // exact: a float32 value
+                        if (a.centered) v = a.depth_pow2 ? (v - df) * a.rdepth_f32 : __fdiv_rn(v - df, a.depth_f32);
+                        y = v;
+                    } else {
+                        const double ct = (double)vlo + ratio[u] * (double)(vhi - vlo);
+                        y = finish_value<VMODE>(a, ct, dd);
+                    }
                 }
+                // np.clip pushed through the monotone tail, then the out-of-FOV padding
+                y = fminf(fmaxf(y, ylo), yhi);
+                res[u] = outb[u] ? ypad : y;
             }
             float *dst = out_tile + out_off + tt * P + k0;
             if (KV == 4) *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1 % KV], res[2 % KV], res[3 % KV]);
             else dst[0] = res[0];
         }
+    };
+
+    // B1: every window that is not area-sampled
+    for (int g = threadIdx.x; g < total; g += kThreads) {
+        const int p = (P4 > 0) ? g / P4 : g / per_win;
+        if (wt.isarea[p]) continue;
+        group(std::false_type{}, p, (g - p * per_win) * KV);
+    }
+    // B2: the area-sampled windows, from the list phase A compacted
+    const int n_area = s_area > 0 ? s_acount : 0;
+    for (int g = threadIdx.x; g < n_area * per_win; g += kThreads) {
+        const int q = (P4 > 0) ? g / P4 : g / per_win;
+        group(std::true_type{}, wt.alist[q], (g - q * per_win) * KV);
     }
 }
 
