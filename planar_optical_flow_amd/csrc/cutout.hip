@@ -159,10 +159,10 @@ __device__ __forceinline__ float finish_value(const CutArgs &a, double ct, doubl
 //               the index range its windows touch and stages only that span of every
 //               row (falls back to L2 gathers when even the span does not fit);
 //            0: gathers straight from global memory
-//   P4       P/4 when it is a compile-time constant (14, 12, 8): the lane ->
-//            (window, k-group) split is then a multiply, and every lane produces
-//            4 consecutive cutout samples -> one float4 store;  0: same with a
-//            runtime P/4;  -1: P % 4 != 0, one sample per lane.
+//   P4       > 0: P/8 as a compile-time constant (7, 6, 4 for P = 56, 48, 32): the lane ->
+//            (window, k-group) split is a multiply and every lane produces 8 consecutive
+//            cutout samples (two float4 stores), which amortises the per-window LDS reads;
+//            0: 4 samples per lane with a runtime P/4;  -1: P % 4 != 0, one sample per lane.
 //   VMODE    0: float64 value path, any depth / centring (bit-exact);
 //            1: same, specialised for centred output with a power-of-two depth (the
 //               reference's configs): (ct - d) * (1/depth);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     };
 
     // ---- phase B ----------------------------------------------------------------
-    constexpr int KV = (P4 >= 0) ? 4 : 1;
+    constexpr int KV = (P4 > 0) ? 8 : (P4 == 0 ? 4 : 1);   // cutout samples per lane and iteration
     const int per_win = (P4 > 0) ? P4 : (P4 == 0 ? P / 4 : P);
     const int total = nwin * per_win;
     const double nm1 = (double)(N - 1);
@@ -373,8 +373,14 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 res[u] = outb[u] ? ypad : y;
             }
             float *dst = out_tile + out_off + tt * P + k0;
-            if (KV == 4) *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1 % KV], res[2 % KV], res[3 % KV]);
-            else dst[0] = res[0];
+            if (KV >= 4) {
+#pragma unroll
+                for (int v = 0; v < KV / 4; ++v)
+                    reinterpret_cast<float4 *>(dst)[v] =
+                        make_float4(res[(4 * v) % KV], res[(4 * v + 1) % KV], res[(4 * v + 2) % KV], res[(4 * v + 3) % KV]);
+            } else {
+                dst[0] = res[0];
+            }
         }
     };
 
@@ -396,9 +402,9 @@ template <int LDSROWS, int FAST, bool DBG>
 void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
 {
     if (!vec4) cutout_kernel<LDSROWS, -1, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
-    else if (a.P == 56) cutout_kernel<LDSROWS, 14, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
-    else if (a.P == 48) cutout_kernel<LDSROWS, 12, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
-    else if (a.P == 32) cutout_kernel<LDSROWS, 8, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 56) cutout_kernel<LDSROWS, 7, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 48) cutout_kernel<LDSROWS, 6, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
+    else if (a.P == 32) cutout_kernel<LDSROWS, 4, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
     else cutout_kernel<LDSROWS, 0, FAST, DBG><<<grid, kThreads, lds, s>>>(a);
 }
 
