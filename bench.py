@@ -349,7 +349,7 @@ def bench_cutout(ops, synth, tab, dev):
 def bench_attention(ops, dev):
     """A10 at DR-SPAAM shape: N=450, F=256*14, E=128, w=11."""
     import torch
-    B, N, E, F = 64, N_PTS, 128, 3584
+    B, N, E, F = 256, N_PTS, 128, 3584
     g = torch.Generator(device=dev).manual_seed(10)
     ex = torch.randn((B, N, E), device=dev, generator=g) * 0.3
     et = torch.randn((B, N, E), device=dev, generator=g) * 0.3

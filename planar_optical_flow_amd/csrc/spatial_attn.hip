@@ -5,7 +5,7 @@
 // multiplies the N x N softmax into the template.  Only the band is non-zero,
 // so both steps are done on the band (O(N*w) instead of O(N^2)):
 //
-//   attn_band_kernel   one wave64 per point: w dot products of length E,
+//   attn_band_kernel   32 points per workgroup, emb rows staged in LDS: w dot products of length E,
 //                      band[b,i,k] = <emb_x[i], emb_t[clamp(i-hw+k)]> (clamped
 //                      duplicates kept, like the reference's gather), masked
 //                      softmax over the DISTINCT in-window columns ->
@@ -25,36 +25,107 @@ namespace {
 
 constexpr int kMaxW = 15;
 
-__global__ __launch_bounds__(256) void attn_band_kernel(const float *emb_x, const float *emb_t, int N,
-                                                        int E, int W, float *band, float *prob)
+// One workgroup = 32 consecutive points of one sample.  The 32 emb_x rows and the
+// 32 + W - 1 emb_t rows they meet are staged in LDS (row stride E+1: lanes that walk
+// consecutive rows hit distinct banks); lane = point, the 4 lane groups split E, every lane
+// keeps its W partial dot products in registers (1 + W LDS reads per W FMAs).  Partial sums
+// meet in LDS, then the first 32 lanes run the masked softmax of their point.
+constexpr int kBandTile = 32;
+constexpr int kBandThreads = 128;
+
+template <int W>
+__global__ __launch_bounds__(kBandThreads) void attn_band_kernel(const float *emb_x, const float *emb_t,
+                                                                 int N, int E, float *band, float *prob)
 {
+    constexpr int HW = W / 2;
+    constexpr int RT = kBandTile + W - 1;   // template rows staged
+    extern __shared__ float s_band[];
+    const int ld = E + 1;
+    float *sx = s_band;                     // [kBandTile][ld]
+    float *st = sx + kBandTile * ld;        // [RT][ld]
+    float *sred = st + RT * ld;             // [4][kBandTile][W]
+
     const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i >= N) return;
-    const int hw = W / 2;
-    const float *ex = emb_x + ((long long)b * N + i) * E;
+    const int i0 = blockIdx.x * kBandTile;
+    const float *ex = emb_x + (long long)b * N * E;
     const float *et = emb_t + (long long)b * N * E;
-    float mine = -INFINITY;
-    for (int k = 0; k < W; ++k) {
-        const int j = min(max(i - hw + k, 0), N - 1);
-        const float *tj = et + (long long)j * E;
-        float part = 0.0f;
-        for (int e = lane; e < E; e += 64) part = fmaf(ex[e], tj[e], part);
-        part = wave_sum_f32(part);
-        if (lane == k) mine = part;
+    if ((E & 3) == 0) {  // rows are 16-B aligned: wide, independent loads, scalar LDS writes (odd row stride)
+        const int E4 = E >> 2;
+#pragma unroll 4
+        for (int e = threadIdx.x; e < kBandTile * E4; e += kBandThreads) {
+            const int r = e / E4, c = e - r * E4;
+            const int row = min(i0 + r, N - 1);
+            const float4 v = reinterpret_cast<const float4 *>(ex + (long long)row * E)[c];
+            float *d = sx + r * ld + 4 * c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+#pragma unroll 4
+        for (int e = threadIdx.x; e < RT * E4; e += kBandThreads) {
+            const int r = e / E4, c = e - r * E4;
+            const int row = min(max(i0 - HW + r, 0), N - 1);   // clamped like the reference's gather
+            const float4 v = reinterpret_cast<const float4 *>(et + (long long)row * E)[c];
+            float *d = st + r * ld + 4 * c;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+        for (int e = threadIdx.x; e < kBandTile * E; e += kBandThreads) {
+            const int r = e / E, c = e - r * E;
+            const int row = min(i0 + r, N - 1);
+            sx[r * ld + c] = ex[(long long)row * E + c];
+        }
+        for (int e = threadIdx.x; e < RT * E; e += kBandThreads) {
+            const int r = e / E, c = e - r * E;
+            const int row = min(max(i0 - HW + r, 0), N - 1);
+            st[r * ld + c] = et[(long long)row * E + c];
+        }
     }
-    const int ju = i - hw + lane;  // unclamped column of this lane's slot
-    const bool slot = lane < W;
-    const bool distinct = slot && ju >= 0 && ju <= N - 1;
-    const float mx = wave_max_f32(slot ? mine : -INFINITY);
-    const float ex_ = distinct ? expf(mine - mx) : 0.0f;
-    const float sum = wave_sum_f32(ex_);
-    if (slot) {
-        const long long o = ((long long)b * N + i) * W + lane;
-        if (band) band[o] = mine;
-        prob[o] = ex_ / sum;
+    __syncthreads();
+    const int pt = threadIdx.x & (kBandTile - 1), grp = threadIdx.x / kBandTile;   // 4 groups
+    const int e0 = grp * ((E + 3) / 4), e1 = min(E, e0 + (E + 3) / 4);
+    float acc[W];
+#pragma unroll
+    for (int k = 0; k < W; ++k) acc[k] = 0.0f;
+    for (int e = e0; e < e1; ++e) {
+        const float xv = sx[pt * ld + e];
+#pragma unroll
+        for (int k = 0; k < W; ++k) acc[k] = fmaf(xv, st[(pt + k) * ld + e], acc[k]);
     }
+#pragma unroll
+    for (int k = 0; k < W; ++k) sred[(grp * kBandTile + pt) * W + k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < kBandTile && i0 + pt < N) {
+        const int i = i0 + pt;
+        float sim[W];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            sim[k] = (sred[pt * W + k] + sred[(kBandTile + pt) * W + k]) +
+                     (sred[(2 * kBandTile + pt) * W + k] + sred[(3 * kBandTile + pt) * W + k]);
+            mx = fmaxf(mx, sim[k]);
+        }
+        float ev[W], sum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const int ju = i - HW + k;  // unclamped column: clamped duplicates get no weight
+            ev[k] = (ju >= 0 && ju <= N - 1) ? expf(sim[k] - mx) : 0.0f;
+            sum += ev[k];
+        }
+        const long long o = ((long long)b * N + i) * W;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            if (band) band[o + k] = sim[k];
+            prob[o + k] = ev[k] / sum;
+        }
+    }
+}
+
+template <int W>
+void launch_band(const float *emb_x, const float *emb_t, int B, int N, int E, float *band, float *prob,
+                 hipStream_t s)
+{
+    const size_t lds = ((size_t)(2 * kBandTile + W - 1) * (E + 1) + 4 * kBandTile * W) * sizeof(float);
+    attn_band_kernel<W><<<dim3((N + kBandTile - 1) / kBandTile, B), kBandThreads, lds, s>>>(emb_x, emb_t, N, E, band,
+                                                                                            prob);
 }
 
 // TRANS = false: forward merge   out[i] = alpha*x[i] + (1-alpha) * sum_k prob[i][k] * tmpl[i-HW+k]
@@ -149,7 +220,7 @@ int dispatch_merge(int W, const float *x, const float *tmpl, const float *prob, 
     // shorter segments (more workgroups, a little halo re-read) for small batches
     const long long colblocks = (F / 4 + 127) / 128;
     int L = N;
-    while (L > 32 && colblocks * ((N + L - 1) / L) * B < 4096) L = (L + 1) / 2;
+    while (L > 32 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
     switch (W) {
         case 1: launch_merge<1, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
         case 3: launch_merge<3, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
@@ -252,7 +323,17 @@ extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, con
     if (B == 0) return POF_OK;
     if (B > 65535) return POF_E_SHAPE;
     hipStream_t s = pof_stream(stream);
-    attn_band_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, N, E, W, band, prob);
+    if ((size_t)(2 * kBandTile + W - 1) * (E + 1) * sizeof(float) > 60 * 1024) return POF_E_SHAPE;  // E <= ~190
+    switch (W) {
+        case 1: launch_band<1>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 3: launch_band<3>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 5: launch_band<5>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 7: launch_band<7>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 9: launch_band<9>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 11: launch_band<11>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        case 13: launch_band<13>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        default: launch_band<15>(emb_x, emb_t, B, N, E, band, prob, s); break;
+    }
     POF_CHECK_LAUNCH();
     const int rc = dispatch_merge<false>(W, x, tmpl, prob, out, nullptr, B, N, F, alpha, s);
     if (rc != POF_OK) return rc;
