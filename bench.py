@@ -296,8 +296,8 @@ def main():
                                   + (", chained (params of batch i+1 ride in the launch of batch i)" if a.chained else "")),
                        "parallelism": "batch-sharded x%d, no collective" % world},
             "epe_vs_oracle_m": epe,
-            "roofline": {"bound": "hbm", "kernel": ("scan_preprocess_chain_kernel<float,2,2>" if a.chained
-                                    else "scan_params_kernel + scan_preprocess_kernel<float,2,2>"),
+            "roofline": {"bound": "hbm", "kernel": ("scan_preprocess_chain_kernel<float,2,1>" if a.chained
+                                    else "scan_params_kernel + scan_preprocess_kernel<float,2,1>"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
