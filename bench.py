@@ -306,6 +306,9 @@ def main():
         if not a.no_extra:
             result["cutout"] = bench_cutout(ops, synth, tab, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
+            # PMC traffic of the same shapes (the profile run executes this very function)
+            result["cutout"]["roofline"]["traffic"] = pmc_traffic(("cutout_",))[0]
+            result["spatial_attention"]["roofline"]["traffic"] = pmc_traffic(("attn_",))[0]
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]

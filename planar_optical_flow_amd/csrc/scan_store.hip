@@ -36,8 +36,9 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float *scans_
     float *dst = out + ((long long)b * T1 + j) * N;
     const bool vec = (N % 4 == 0) && (((uintptr_t)src & 15) == 0) && (((uintptr_t)dst & 15) == 0);
     if (vec) {
+        using F4V = float __attribute__((ext_vector_type(4)));
         for (int e = threadIdx.x; e < N / 4; e += blockDim.x)
-            reinterpret_cast<float4 *>(dst)[e] = reinterpret_cast<const float4 *>(src)[e];
+            __builtin_nontemporal_store(reinterpret_cast<const F4V *>(src)[e], reinterpret_cast<F4V *>(dst) + e);
     } else if ((N % 2 == 0) && (((uintptr_t)src & 7) == 0) && (((uintptr_t)dst & 7) == 0)) {
         for (int e = threadIdx.x; e < N / 2; e += blockDim.x)
             reinterpret_cast<float2 *>(dst)[e] = reinterpret_cast<const float2 *>(src)[e];

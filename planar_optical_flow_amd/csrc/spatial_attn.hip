@@ -132,6 +132,20 @@ void launch_band(const float *emb_x, const float *emb_t, int B, int N, int E, fl
 // TRANS = true : backward wrt the template, driven by the output gradient g (= `tmpl` argument):
 //                out[j]  = (1-alpha) * sum_k prob[j-HW+k][W-1-k] * g[j-HW+k]     (d tmpl)
 //                out2[j] = alpha * g[j]                                          (d x)
+// x is read once and the outputs are written once: streaming loads / stores keep them from
+// evicting the template rows that neighbouring segments re-read from L2.
+using F4V = float __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void stream_store(float4 *p, const float4 &v)
+{
+    F4V t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<F4V *>(p));
+}
+__device__ __forceinline__ float4 stream_load(const float4 *p)
+{
+    const F4V t = __builtin_nontemporal_load(reinterpret_cast<const F4V *>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 template <int W, bool TRANS>
 __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const float4 *tmpl,
                                                          const float *prob, float4 *out, float4 *out2,
@@ -185,15 +199,15 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
                         const float4 gv = win[(u + HW + 1) % W];  // row i itself
                         o = make_float4(one_minus_alpha * acc.x, one_minus_alpha * acc.y, one_minus_alpha * acc.z,
                                         one_minus_alpha * acc.w);
-                        O2[(long long)i * F4] = make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w);
+                        stream_store(O2 + (long long)i * F4, make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w));
                     } else {
-                        const float4 xv = X[(long long)i * F4];
+                        const float4 xv = stream_load(X + (long long)i * F4);
                         o.x = alpha * xv.x + one_minus_alpha * acc.x;
                         o.y = alpha * xv.y + one_minus_alpha * acc.y;
                         o.z = alpha * xv.z + one_minus_alpha * acc.z;
                         o.w = alpha * xv.w + one_minus_alpha * acc.w;
                     }
-                    O[(long long)i * F4] = o;
+                    stream_store(O + (long long)i * F4, o);
                 }
             }
         }

@@ -46,8 +46,8 @@ if "attn" in which:
         x = torch.randn((B, N, F), device=dev, generator=g)
         t = torch.randn((B, N, F), device=dev, generator=g)
         out = torch.empty_like(x)
-        ms = timeit(lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), iters=10)
         per = 3 * N * F * 4 + 2 * N * E * 4 + 2 * N * 11 * 4
+        ms = timeit(lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), iters=10)
         print("attn B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
 if "corr" in which:
     for (B, C, n) in [(4096, 256, 57), (256, 256, 450)]:
