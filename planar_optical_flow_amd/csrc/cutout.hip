@@ -310,18 +310,44 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
         const double kd0 = (double)k0;
-        double ratio[KV];
+        using RatioT = typename std::conditional<VMODE == 2, float, double>::type;
+        RatioT ratio[KV];
         int lo[KV];
         bool outb[KV];
+        if (VMODE == 2) {
+            // Approximate-then-verify index: idx' = c0 + k*c1 with c0 = (a0-phi0)/dphi, c1 = step/dphi
+            // is within 3e-12 of the reference's rounding sequence (N <= 4096), so floor, fract and
+            // the range tests agree with it unless idx' is within 1e-6 of an integer; only those
+            // lanes (2e-6 of all samples) run the exact sequence.  One float64 FMA instead of five.
+            const double c1 = step * rdphi;
+            const double base = fma(kd0, c1, (a0 - phi0) * rdphi);
 #pragma unroll
-        for (int u = 0; u < KV; ++u) {
-            const double idx = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
-            // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
-            outb[u] = (__double2hiint(idx) < 0) || (idx > nm1);
-            // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
-            // range the value is replaced by the padding, only the address must stay legal
-            lo[u] = min(max((int)idx, 0), N - 1);
-            ratio[u] = __builtin_amdgcn_fract(idx);
+            for (int u = 0; u < KV; ++u) {
+                const double idx = fma((double)u, c1, base);
+                float rf = (float)__builtin_amdgcn_fract(idx);
+                int l = (int)idx;
+                bool ob = (__double2hiint(idx) < 0) || (l >= N - 1);
+                if (!(rf >= 1e-6f && rf <= 1.0f - 1e-6f)) {   // near an integer (or NaN): exact sequence
+                    const double ie = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
+                    ob = (__double2hiint(ie) < 0) || (ie > nm1);
+                    l = (int)ie;
+                    rf = (float)__builtin_amdgcn_fract(ie);
+                }
+                outb[u] = ob;
+                lo[u] = min(max(l, 0), N - 1);
+                ratio[u] = rf;
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < KV; ++u) {
+                const double idx = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
+                // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
+                outb[u] = (__double2hiint(idx) < 0) || (idx > nm1);
+                // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
+                // range the value is replaced by the padding, only the address must stay legal
+                lo[u] = min(max((int)idx, 0), N - 1);
+                ratio[u] = __builtin_amdgcn_fract(idx);
+            }
         }
         if (DBG) {
             const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
@@ -331,6 +357,12 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                     a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
         }
         const double step_a = AREA ? wt.step_a[p] : 0.0;
+        // fixed-point scale of the area index: 19 fractional bits while (N + 1) * 2^19 < 2^31
+        const int area_sh = (N <= 4000) ? 19 : ((N <= 64000) ? 15 : 0);
+        const int area_mask = (1 << area_sh) - 1;
+        const double area_scale = (double)(1 << area_sh);
+        const double area_c1 = (AREA && VMODE == 2) ? step_a * rdphi * area_scale : 0.0;
+        const double area_c0 = (AREA && VMODE == 2) ? ((a0 - phi0) * rdphi + 0.5) * area_scale : 0.0;
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
@@ -340,12 +372,32 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 if (AREA) {
                     // mean of s_area nearest-neighbour samples: float32 sum in order, float32 divide
                     float acc = 0.0f;
-                    for (int s = 0; s < s_area; ++s) {
-                        double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
-                        ia = ia < 0.0 ? 0.0 : ia;
-                        ia = ia > nm1 ? nm1 : ia;
-                        const float v = fetch(roff + (int)rint(ia));
-                        acc = (s == 0) ? v : acc + v;
+                    if (VMODE == 2) {
+                        // rint(clip(ia)) as a fixed-point floor of ia + 0.5: one FMA and one
+                        // saturating conversion per area sample; lanes within 2^-(sh-1) of a tie
+                        // (or out of fixed-point range) take the exact sequence
+                        const double ub = fma((double)((k0 + u) * s_area), area_c1, area_c0);
+                        for (int s = 0; s < s_area; ++s) {
+                            const int q = (int)fma((double)s, area_c1, ub);
+                            int ri = q >> area_sh;
+                            const int fb = q & area_mask;
+                            if (fb < 2 || fb > area_mask - 2 || area_sh == 0) {
+                                double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
+                                ia = ia < 0.0 ? 0.0 : ia;
+                                ia = ia > nm1 ? nm1 : ia;
+                                ri = (int)rint(ia);
+                            }
+                            const float v = fetch(roff + min(max(ri, 0), N - 1));
+                            acc = (s == 0) ? v : acc + v;
+                        }
+                    } else {
+                        for (int s = 0; s < s_area; ++s) {
+                            double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
+                            ia = ia < 0.0 ? 0.0 : ia;
+                            ia = ia > nm1 ? nm1 : ia;
+                            const float v = fetch(roff + (int)rint(ia));
+                            acc = (s == 0) ? v : acc + v;
+                        }
                     }
                     const float mean_a = __fdiv_rn(acc, (float)s_area);
                     if (VMODE == 2) {
@@ -415,8 +467,9 @@ void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool 
 {
     const bool fast = a.centered && a.depth_pow2;
     if (a.dbg_lo) {
-        // test-only variant, no need to specialise further
-        launch_cutout2<LDSROWS, 0, true>(a, grid, lds, s, vec4);
+        // test-only variants, no need to specialise further
+        if (a.value_mode == 1) launch_cutout2<LDSROWS, 2, true>(a, grid, lds, s, vec4);
+        else launch_cutout2<LDSROWS, 0, true>(a, grid, lds, s, vec4);
     } else if (a.value_mode == 1) {
         launch_cutout2<LDSROWS, 2, false>(a, grid, lds, s, vec4);
     } else if (fast) {

@@ -533,17 +533,38 @@ def test_chained_preprocess_equals_two_launch_form(ops):
             assert torch.equal(got[k], ref[i][k]), (i, k)
 
 
-@pytest.mark.parametrize("name", ["dr_spaam", "config_test", "stride2", "near"])
+@pytest.mark.parametrize("name", sorted(CUTOUT_CASES))
 def test_cutout_float32_value_path(ops, golden, name):
-    """value_mode 1: indices exact (same debug tensor), values within 1e-5 of the exact path."""
+    """value_mode 1 (approximate-then-verify index, float32 lerp): inds_ct_low identical to the
+    exact path, values within 1e-5 of it, saturated samples exactly +-1."""
     g = golden("cutout")
     inc, n, kw = CUTOUT_CASES[name]
     tab = ops.phi_table(np.radians(inc), n)
     scans = T(g[name + "_scans"])
-    exact = ops.cutout(scans, tab, **kw)
-    fast = ops.cutout(scans, tab, exact_values=False, **kw)
+    exact, dbg_e = ops.cutout(scans, tab, return_debug=True, **kw)
+    fast, dbg_f = ops.cutout(scans, tab, exact_values=False, return_debug=True, **kw)
+    assert torch.equal(dbg_e["lo"], dbg_f["lo"])
+    plain = ops.cutout(scans, tab, exact_values=False, **kw)       # the non-debug instantiation
+    assert torch.equal(plain, fast)
     err = (exact - fast).abs().max().item()
     assert err <= 1e-5, err
     sat = exact.abs() == 1.0
     if kw.get("centered", True):
         assert torch.equal(fast[sat], exact[sat])          # saturated samples are exactly +-1
+
+
+def test_cutout_float32_value_path_large(ops):
+    """Same contract on 1.3e8 samples (2048 x 450 x 5 x 56, near-field legs included): the
+    verify step must catch every index within rounding distance of an integer."""
+    sb = synth.make_batch(seed=33, B=2048, T=5)
+    scans = T(sb.scans)
+    scans[::7, :, ::50] = 0.05          # near-field returns: wide, area-sampled windows
+    tab = ops.phi_table()
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+              padding_val=29.99, area_mode=True)
+    exact = ops.cutout(scans, tab, **kw)
+    fast = ops.cutout(scans, tab, exact_values=False, **kw)
+    diff = (exact - fast).abs()
+    assert diff.max().item() <= 1e-5, diff.max().item()
+    # an index off by one would move a sample by a whole range step: count anything above 1e-5
+    assert int((diff > 1e-5).sum()) == 0
