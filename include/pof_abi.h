@@ -302,6 +302,20 @@ int pof_associate_odometry(const float *scans_t, const float *odoms_t, const flo
                            const int32_t *row_prev, int B, double *odom0, double *odom1,
                            int32_t *idx0, int32_t *idx1, pof_stream_t stream);
 
+/* ----------------------------------------------------------------------
+ * N1, host side: numeric CSV -> float64 matrix (no device work, no stream).
+ * Replaces np.genfromtxt(path, delimiter=",") for the DROW sequence files
+ * (src/utils/dataset_dr_spaam.py:473-478 `.csv`, :504-509 `.odom2`, :497-502
+ * `.difodom`; bin/data_prepare.py:70-72 `.flow`).  Fields are converted with
+ * strtod (correctly rounded, = Python float()); blank lines and `#` lines are
+ * skipped, empty / unparsable fields become NaN.  pof_csv_shape reports the
+ * row count and the column count of the first row; pof_csv_read_f64 fills a
+ * caller-owned [rows][cols] buffer (POF_E_SHAPE if the file does not have
+ * exactly that shape on every row); threads <= 0: one per hardware thread (max 16).
+ * ---------------------------------------------------------------------- */
+int pof_csv_shape(const char *path, long long *rows, int *cols);
+int pof_csv_read_f64(const char *path, long long rows, int cols, double *out, int threads);
+
 #ifdef __cplusplus
 }
 #endif

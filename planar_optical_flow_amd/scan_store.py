@@ -6,9 +6,10 @@ call in DataLoader workers.  ``DROWDeviceDataset`` holds the same sequences
 concatenated in HBM and produces a whole collated batch with four launches
 (window gather, odometry association, fused preprocess, cutout).
 
-File parsing (csv / .odom2 / json detection files) is out of scope: the
-constructor takes the already-parsed arrays, exactly the tuples the reference's
-``_load_scan_file`` / ``_load_odom`` / ``_load_det_file`` return.  The one-time
+The constructor takes parsed arrays, exactly the tuples the reference's
+``_load_scan_file`` / ``_load_odom`` / ``_load_det_file`` return; ``from_files``
+parses a DROW split directory (``drow_io``: the library's CSV reader instead of
+``np.genfromtxt``) and ``from_pack`` reads the one-file binary pack.  The one-time
 index building of the reference's ``__init__`` (static-scene filter :277-290,
 detection -> scan map :320-334) is restated here on the host with NumPy; it is
 bookkeeping over a few thousand integers, not per-sample compute.
@@ -32,6 +33,7 @@ class DROWDeviceDataset:
         scans, scans_t, odoms, odoms_t = [], [], [], []
         self._seq_first, self._odom_lo, self._odom_hi = [], [], []
         self._samples = []  # (sequence, scan index in sequence, wc, wa, wp)
+        self.seq_names = []  # sequences that survived the static-scene filter (reference: self.seq_names)
         row0 = odom0 = 0
         for seq in sequences:
             od, od_t = np.asarray(seq["odoms"], np.float32), np.asarray(seq["odoms_t"], np.float32)
@@ -46,6 +48,7 @@ class DROWDeviceDataset:
                 od, od_t = od[keep], od_t[keep]
                 sc, sc_t, sc_ns = sc[keep], sc_t[keep], sc_ns[keep]
             s_idx = len(self._seq_first)
+            self.seq_names.append(seq.get("name", str(s_idx)))
             self._seq_first.append(row0)
             self._odom_lo.append(odom0)
             self._odom_hi.append(odom0 + len(od))
@@ -68,8 +71,27 @@ class DROWDeviceDataset:
         self.odoms = torch.from_numpy(np.concatenate(odoms)).to(dev)
         self.odoms_t = torch.from_numpy(np.concatenate(odoms_t)).to(dev)
 
+    @classmethod
+    def from_files(cls, data_path, split="train", max_sequences=5, **kw):
+        """The reference's ``DROWDataset2(data_path, split, ...)`` constructor (dataset_dr_spaam.py:256-334):
+        parse `<data_path>/<split>/*.{csv,odom2,wc,wa,wp}`, drop static stretches, index the annotated
+        frames.  Sequences are taken in sorted order (the reference uses directory order)."""
+        from . import drow_io
+        return cls(drow_io.load_sequences(data_path, split, max_sequences), **kw)
+
+    @classmethod
+    def from_pack(cls, path, **kw):
+        from . import drow_io
+        return cls(drow_io.load_pack(path), **kw)
+
     def __len__(self):
         return len(self._samples)
+
+    @property
+    def sample_index(self):
+        """(sequence index, scan index within the filtered sequence) per sample: the reference's
+        ``flat_seq_inds`` and ``idet2iscan[seq][flat_det_inds]``."""
+        return [(s[0], s[1]) for s in self._samples]
 
     def get_batch(self, indices):
         """The collated batch dict of ``collate_batch([ds[i] for i in indices])``: device tensors for the

@@ -229,3 +229,64 @@ def test_device_dataset_static_filter():
     assert ds.scans.shape[0] == int(keep.sum())
     kept_ns = np.arange(S)[keep]
     assert len(ds) == sum(1 for d in range(0, S, 2) if d in kept_ns)
+
+
+def test_device_dataset_from_files_equals_reference(golden, tmp_path):
+    """N1 end to end: DROW text files -> (library CSV reader, static-scene filter, annotated-frame
+    index) -> device store -> batch, against the reference's DROWDataset2(data_path, split)
+    constructor + __getitem__ + collate_batch run on the same files."""
+    import os
+    from dataset_fixture import CUTOUT_KW
+    from test_oracle_golden import _write_drow_files
+    from planar_optical_flow_amd import drow_io
+    from planar_optical_flow_amd.scan_store import DROWDeviceDataset
+    g = golden("dataset_files")
+    _write_drow_files(g, str(tmp_path))
+    ds = DROWDeviceDataset.from_files(str(tmp_path), "train", num_scans=5, cutout_kwargs=CUTOUT_KW)
+    ref_names = [str(x) for x in g["ds_seq_names"]]
+    mine = [os.path.basename(n) for n in ds.seq_names]
+    assert sorted(mine) == sorted(ref_names) == ["run_a", "run_b"]       # run_static is dropped by both
+    # the reference lists samples sequence by sequence in its directory order: map to ours
+    ref_flat = [(ref_names[s], int(i)) for s, i in zip(g["ds_flat_seq"], g["ds_flat_scan"])]
+    my_flat = [(mine[s], i) for s, i in ds.sample_index]
+    assert sorted(ref_flat) == sorted(my_flat)
+    order = [my_flat.index(x) for x in ref_flat]
+    batch = ds.get_batch(order)
+    assert torch.equal(batch["scans"].cpu(), torch.from_numpy(g["out_scans"]))
+    assert np.array_equal(batch["odom1"].cpu().numpy().astype(np.float32), g["out_odom1"])
+    assert np.array_equal(batch["target_cls"].cpu().numpy(), g["out_target_cls"])
+    np.testing.assert_allclose(batch["target_reg"].cpu().numpy(), g["out_target_reg"], atol=1e-6)
+    np.testing.assert_allclose(batch["target_flow"].cpu().numpy(), g["out_target_flow"], atol=5e-6)
+    assert np.array_equal(batch["exclude_mask"].cpu().numpy().astype(np.float64), g["out_exclude_mask"])
+    got = batch["input"][:2].cpu().numpy()
+    assert np.mean(np.abs(got - g["out_input_first2"]) > 1e-4) < 2e-3
+    # the binary pack feeds the same store
+    ds2 = DROWDeviceDataset.from_pack(drow_io.pack_split(str(tmp_path), "train"), num_scans=5, cutout_kwargs=CUTOUT_KW)
+    b2 = ds2.get_batch(order)
+    for k in ("scans", "target_cls", "target_flow", "input"):
+        assert torch.equal(b2[k], batch[k]), k
+
+
+def test_prepare_sequence_matches_data_prepare(golden, tmp_path):
+    """bin/data_prepare.py: `.difodom` text and `.flow` values (oracle prepared_flow_target on the
+    re-read, rounded differences)."""
+    import os
+    from test_oracle_golden import _write_drow_files
+    from planar_optical_flow_amd import drow_io
+    g = golden("dataset_files")
+    d, _ = _write_drow_files(g, str(tmp_path))
+    base = os.path.join(d, "run_a")
+    flow = drow_io.prepare_sequence(base)
+    _, odom_t, odom = drow_io.load_odom(base)
+    dt = np.concatenate((odom_t[1:] - odom_t[:-1], [0]))
+    dd = np.concatenate((odom[1:] - odom[:-1], [[0] * 3]))
+    import io
+    buf = io.StringIO()
+    np.savetxt(buf, np.hstack([dt.reshape(-1, 1), dd]), fmt="%8.6f", delimiter=",")
+    assert open(base + ".difodom").read() == buf.getvalue()
+    t_r, d_r = drow_io.load_odom_file(base)
+    _, _, scans = drow_io.load_scan_file(base)
+    phi = R.laser_phi()
+    ref = np.stack([R.prepared_flow_target(scans[i], phi, t_r[i], d_r[i]) for i in range(len(scans))])
+    np.testing.assert_allclose(flow, ref, atol=1e-12)
+    np.testing.assert_allclose(drow_io.load_flow_file(base), ref, atol=6e-9)   # %10.8f text

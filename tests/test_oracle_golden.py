@@ -202,3 +202,79 @@ def test_n1_dataset_getitem(golden):
             assert np.array_equal(it["input"], g["out_input_first3"][i])
     # the window really clamps at the sequence start for early scans
     assert R.window_indices(3) == [0, 0, 0, 0, 0] and R.window_indices(12) == [3, 4, 5, 6, 7]
+
+
+# ---- N1: DROW file formats (host side; needs the library's CSV reader, no GPU) -------------
+def _write_drow_files(g, root):
+    import os
+    d = os.path.join(root, "train")
+    os.makedirs(d)
+    names = sorted({k.split("_", 2)[1] + "_" + k.split("_", 2)[2].rsplit("_", 1)[0]
+                    for k in g.files if k.startswith("file_")})
+    for k in g.files:
+        if k.startswith("file_"):
+            stem, ext = k[len("file_"):].rsplit("_", 1)
+            with open(os.path.join(d, stem + "." + ext), "wb") as f:
+                f.write(g[k].tobytes())
+    return d, sorted({k[len("file_"):].rsplit("_", 1)[0] for k in g.files if k.startswith("file_")})
+
+
+def test_drow_loaders_equal_reference(golden, tmp_path):
+    """load_scan_file / load_odom / load_det_file vs the reference's np.genfromtxt / json loaders
+    run on the same files (bit-identical values and dtypes)."""
+    import os
+    from planar_optical_flow_amd import drow_io
+    g = golden("dataset_files")
+    d, names = _write_drow_files(g, str(tmp_path))
+    assert names == ["run_a", "run_b", "run_static"]
+    for nm in names:
+        base = os.path.join(d, nm)
+        ns, t, sc = drow_io.load_scan_file(base)
+        for got, key in ((ns, "scan_ns_"), (t, "scan_t_"), (sc, "scan_")):
+            assert got.dtype == g[key + nm].dtype and np.array_equal(got, g[key + nm]), key + nm
+        ns, t, od = drow_io.load_odom(base)
+        for got, key in ((ns, "odom_ns_"), (t, "odom_t_"), (od, "odom_")):
+            assert got.dtype == g[key + nm].dtype and np.array_equal(got, g[key + nm]), key + nm
+        dns, wc, wa, wp = drow_io.load_det_file(base)
+        assert np.array_equal(dns, g["det_ns_" + nm])
+        for tag, lst in (("wc", wc), ("wa", wa), ("wp", wp)):
+            assert [len(x) for x in lst] == list(g["det_%s_cnt_%s" % (tag, nm)])
+            flat = np.array([v for x in lst for v in x], dtype=np.float64).reshape(-1, 2)
+            assert np.array_equal(flat, g["det_%s_val_%s" % (tag, nm)])
+
+
+def test_drow_csv_reader_edge_cases(tmp_path):
+    from planar_optical_flow_amd import drow_io
+    p = tmp_path / "x.csv"
+    p.write_text("# comment\n1, 2.5 ,-3e-2\n\n4,,1e400\r\n7,abc,0.1")
+    got = drow_io.read_csv(str(p))
+    ref = np.genfromtxt(str(p), delimiter=",")
+    assert got.shape == (3, 3)
+    assert np.array_equal(got, ref, equal_nan=True)
+    ragged = tmp_path / "r.csv"
+    ragged.write_text("1,2,3\n4,5\n")
+    with pytest.raises(Exception):
+        drow_io.read_csv(str(ragged))
+    with pytest.raises(FileNotFoundError):
+        drow_io.read_csv(str(tmp_path / "missing.csv"))
+    # many rows: the threaded path gives the same matrix as genfromtxt
+    rng = np.random.default_rng(0)
+    big = rng.uniform(-30, 30, (500, 12))
+    bp = tmp_path / "big.csv"
+    np.savetxt(str(bp), big, fmt="%.7g", delimiter=",")
+    assert np.array_equal(drow_io.read_csv(str(bp)), np.genfromtxt(str(bp), delimiter=","))
+
+
+def test_drow_pack_round_trip(golden, tmp_path):
+    from planar_optical_flow_amd import drow_io
+    g = golden("dataset_files")
+    d, _ = _write_drow_files(g, str(tmp_path))
+    seqs = drow_io.load_sequences(str(tmp_path), "train")
+    path = drow_io.pack_split(str(tmp_path), "train")
+    back = drow_io.load_pack(path)
+    assert len(back) == len(seqs) == 3
+    for a, b in zip(seqs, back):
+        for k in ("scans_ns", "scans_t", "scans", "odoms_t", "odoms", "dets_ns"):
+            assert np.array_equal(np.asarray(a[k]), np.asarray(b[k])), k
+        for k in ("dets_wc", "dets_wa", "dets_wp"):
+            assert a[k] == b[k], k

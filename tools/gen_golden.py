@@ -305,6 +305,69 @@ def main():
     gd["out_input_first3"] = coll["input"][:3]
     np.savez_compressed(os.path.join(OUT, "dataset_items.npz"), **gd)
 
+    # ---------------- N1: the reference's file loaders and its __init__ from files ----------
+    # Synthetic DROW-format text files (written to a temp dir; their bytes are stored in the
+    # fixture so the test can re-create them), parsed by the reference's own loaders, then the
+    # reference's real DROWDataset2(data_path, split) -> __getitem__ -> collate_batch.
+    import tempfile, json as _json
+    rng = np.random.default_rng(72)
+    tmp = tempfile.mkdtemp(prefix="pof_drow_")
+    os.makedirs(os.path.join(tmp, "train"))
+    gf = {}
+    names = ["run_a", "run_b", "run_static"]
+    for q, nm in enumerate(names):
+        S = (31, 26, 12)[q]
+        sbq = synth.make_batch(seed=400 + q, B=S, T=1)
+        sc = sbq.scans[:, 0]
+        ns = np.arange(100 * (q + 1), 100 * (q + 1) + S)
+        st = np.arange(S) * 0.08 + 1.5 + 0.01 * q
+        od = np.cumsum(rng.uniform(-0.02, 0.02, (S, 3)), axis=0)
+        if nm == "run_static":
+            od[:] = od[0]                      # dropped by the static-scene filter
+        else:
+            od[7] = od[6]                      # one repeated odometry row inside a moving sequence
+        base = os.path.join(tmp, "train", nm)
+        with open(base + ".csv", "w") as f:
+            for i in range(S):
+                f.write("%d,%.6f,%s\n" % (ns[i], st[i], ",".join("%.3f" % v for v in sc[i])))
+        with open(base + ".odom2", "w") as f:
+            for i in range(S):
+                f.write("%d,%.6f,%.6f,%.6f,%.6f\n" % (ns[i], st[i] - 0.004, od[i, 0], od[i, 1], od[i, 2]))
+        dns = ns[2::3]
+        for ext in ("wc", "wa", "wp"):
+            with open(base + "." + ext, "w") as f:
+                for d in dns:
+                    k = int(rng.integers(0, 3))
+                    dets = [[round(float(rng.uniform(1, 8)), 3), round(float(rng.uniform(-1.6, 1.6)), 4)] for _ in range(k)]
+                    f.write("%d,%s\n" % (d, _json.dumps(dets)))
+        for ext in ("csv", "odom2", "wc", "wa", "wp"):
+            gf["file_%s_%s" % (nm, ext)] = np.frombuffer(open(base + "." + ext, "rb").read(), dtype=np.uint8)
+        lo = DROWDataset2.__new__(DROWDataset2)
+        a, b, c = lo._load_scan_file(base)
+        gf["scan_ns_" + nm], gf["scan_t_" + nm], gf["scan_" + nm] = a, b, c
+        a, b, c = lo._load_odom(base)
+        gf["odom_ns_" + nm], gf["odom_t_" + nm], gf["odom_" + nm] = a, b, c
+        a, wcs, was, wps = lo._load_det_file(base)
+        gf["det_ns_" + nm] = a
+        for tag, lst in (("wc", wcs), ("wa", was), ("wp", wps)):
+            gf["det_%s_cnt_%s" % (tag, nm)] = np.array([len(x) for x in lst], dtype=np.int32)
+            gf["det_%s_val_%s" % (tag, nm)] = np.array([v for x in lst for v in x], dtype=np.float64).reshape(-1, 2)
+    ckw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+               padding_val=29.99, area_mode=True)
+    ds3 = DROWDataset2(tmp, split="train", num_scans=5, network_type="cutout", cutout_kwargs=ckw)
+    gf["ds_seq_names"] = np.array([os.path.basename(n) for n in ds3.seq_names])
+    gf["ds_flat_seq"] = np.array(ds3.flat_seq_inds, dtype=np.int32)
+    gf["ds_flat_scan"] = np.array([ds3.idet2iscan[s][d] for s, d in zip(ds3.flat_seq_inds, ds3.flat_det_inds)],
+                                  dtype=np.int32)
+    coll3 = ds3.collate_batch([ds3[i] for i in range(len(ds3))])
+    for k in ("scans", "target_cls", "target_reg", "target_flow", "exclude_mask"):
+        gf["out_" + k] = coll3[k]
+    gf["out_odom1"] = np.array(coll3["odom1"])
+    gf["out_input_first2"] = coll3["input"][:2]
+    np.savez_compressed(os.path.join(OUT, "dataset_files.npz"), **gf)
+    import shutil
+    shutil.rmtree(tmp)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
