@@ -306,9 +306,11 @@ def main():
         if not a.no_extra:
             result["cutout"] = bench_cutout(ops, synth, tab, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
+            result["band_correlation"] = bench_band_corr(ops, dev)
             # PMC traffic of the same shapes (the profile run executes this very function)
             result["cutout"]["roofline"]["traffic"] = pmc_traffic(("cutout_",))[0]
             result["spatial_attention"]["roofline"]["traffic"] = pmc_traffic(("attn_",))[0]
+            result["band_correlation"]["roofline"]["traffic"] = pmc_traffic(("band_corr_",))[0]
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
@@ -365,6 +367,24 @@ def bench_attention(ops, dev):
     return {"workload": "spatial attention N=450 F=3584 E=128 w=11, batch %d" % B, "ms_per_call": ms,
             "roofline": {"bound": "hbm", "kernel": "attn_band_kernel + attn_merge_kernel<11>", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+def bench_band_corr(ops, dev):
+    """A9 at the Prototype shape: C=256 channels, n=57 positions, kernel 3, max displacement 5."""
+    import torch
+    B, C, n, D = 4096, 256, 57, 11
+    g = torch.Generator(device=dev).manual_seed(9)
+    f1 = torch.randn((B, C, n), device=dev, generator=g)
+    f2 = torch.randn((B, C, n), device=dev, generator=g)
+    out = torch.empty((B, D, n), dtype=torch.float32, device=dev)
+    ms = _time_kernel(torch, lambda: ops.band_correlation(f1, f2, 3, 5, out=out), 20)
+    per = 2 * C * n * 4 + D * n * 4
+    ach = per * B / (ms * 1e-3) / 1e9
+    return {"workload": "band correlation C=256 n=57 k=3 maxdisp=5, batch %d" % B, "ms_per_call": ms,
+            "mfma_tflops": B * 2.0 * 64 * 64 * C / (ms * 1e-3) / 1e12,
+            "roofline": {"bound": "hbm", "kernel": "band_corr_small_kernel<3> (float32 MFMA 32x32x2 Gram block)",
+                         "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                         "traffic": None}}
 
 
 if __name__ == "__main__":

@@ -7,93 +7,227 @@
 // what keeps BASELINE config 5 (n = 450) HBM-bound: algorithmic bytes per
 // sample 2*C*n*4 read + D*n*4 written (119 244 B at C=256, n=57), 8 flop/B.
 //
-// One workgroup = one sample x 64 consecutive points; 4 wave64s split the
-// channels, each lane owns one point and keeps its D accumulators in registers.
-// Channel chunks are staged through LDS ([c][position], lanes read consecutive
-// addresses -> conflict free).  float32 multiply-add, like torch.matmul.
+// Forward: float32 MFMA on the per-position Gram matrix, band extracted from LDS (below).
 #include "pof_common.h"
 
 namespace {
 
-constexpr int kTile = 64;    // points per workgroup (= lanes per wave)
-constexpr int kGroups = 4;   // channel groups (= waves)
-constexpr int kChunk = 32;   // channels staged per pass
+// The banded correlation is a band of the per-position Gram matrix
+//   P[a][b] = sum_c f1[c][a] * f2[c][b],     out[d][i] = sum_k P[A(i,k)][Bc(i,d,k)]
+// with A = clamp(i+k-hk), Bc = clamp(clamp(i+d-md)+k-hk), and a 32 x 64 block of P is
+// exactly what two float32 MFMAs per channel pair produce: v_mfma_f32_32x32x2_f32 takes ONE
+// float per lane for each operand, lane l -> A[row l&31][k = l>>5], B[k = l>>5][col l&31], so
+// the operands are plain coalesced global loads of the [C][n] rows (lanes 0-31 channel c,
+// lanes 32-63 channel c+1) -- no LDS staging, no per-element VALU work.  Numerics: a k-ordered
+// float32 fmaf chain over the channels (exact float32 products, one rounding per step).
+//
+// One wave = one sample x PTS = 32-(K-1) consecutive points: rows [i0-hk, i0-hk+32) of P
+// against columns [i0-md-hk, i0-md-hk+64); positions outside [0, n) load as 0 and are never
+// read back (the clamps stay inside the valid range).  The two accumulator tiles go to LDS
+// and each lane sums K entries per output.  2.2x the band's flops, on the matrix pipe, which
+// leaves the kernel HBM-bound: algorithmic bytes per sample 2*C*n*4 + D*n*4.
+constexpr int kWavesPerBlock = 4;
 constexpr int kMaxD = 15;    // max 2*max_disp+1
 constexpr int kMaxK = 5;     // max kernel_size
+constexpr int kPld = 65;     // LDS row stride of the staged 32 x 64 block of P
 
-template <int K, int D>
-__global__ __launch_bounds__(kTile *kGroups) void band_corr_kernel(const float *f1, const float *f2,
-                                                                   float *out, int C, int n)
+using f32x16 = float __attribute__((ext_vector_type(16)));
+
+template <int K>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const float *f1, const float *f2,
+                                                                        float *out, int B, int C, int n, int D,
+                                                                        int nblk)
 {
-    constexpr int HK = K / 2, MD = D / 2;
-    constexpr int W1 = kTile + 2 * HK;            // staged f1 positions
-    constexpr int W2 = kTile + 2 * (MD + HK);     // staged f2 positions
-    __shared__ float s1[kChunk][W1];
-    __shared__ float s2[kChunk][W2];
-    __shared__ float s_red[kGroups][D][kTile];
-
-    const int b = blockIdx.y;
-    const int i0 = blockIdx.x * kTile;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int i = i0 + lane;
+    constexpr int HK = K / 2;
+    constexpr int PTS = 32 - (K - 1);
+    __shared__ float s_p[kWavesPerBlock][32 * kPld];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int unit_raw = blockIdx.x * kWavesPerBlock + wave;  // (sample, point block)
+    const bool live = unit_raw < B * nblk;                    // tail waves recompute the last unit, store nothing
+    const int unit = live ? unit_raw : B * nblk - 1;
+    const int b = unit / nblk, blk = unit - b * nblk;
+    const int MD = D / 2;
+    const int i0 = blk * PTS;
+    const int ra = i0 - HK, cb = i0 - MD - HK;
+    const int r = lane & 31, h = lane >> 5;
+    // wave-uniform bases (scalar registers) + 32-bit per-lane offsets: global_load with an
+    // SGPR base needs no 64-bit address VGPRs per load
     const float *g1 = f1 + (long long)b * C * n;
     const float *g2 = f2 + (long long)b * C * n;
-    const bool interior = (i - MD >= 0) && (i + MD <= n - 1);
+    const int pa = ra + r, pb0 = cb + r, pb1 = cb + 32 + r;
+    const bool va = pa >= 0 && pa < n, vb0 = pb0 >= 0 && pb0 < n, vb1 = pb1 >= 0 && pb1 < n;
+    // clamped positions keep the masked lanes' (unused) loads inside the sample
+    const int la = min(max(pa, 0), n - 1), l0 = min(max(pb0, 0), n - 1), l1 = min(max(pb1, 0), n - 1);
+    const int hoff = h * n;   // upper half-wave: the odd channel of the pair
 
-    float acc[D];
+    f32x16 acc0 = {0}, acc1 = {0};
+    // Channel pairs in blocks of U, register double-buffered: the loads of block k+1 are issued
+    // before the 2U MFMAs of block k (one MFMA = 64 cycles, so a block covers ~1000 cycles of
+    // memory latency per wave).  Indices past the end are clamped for the load and zeroed for
+    // the MFMA; an odd last channel feeds zeros from the upper half-wave.
+    constexpr int U = 8;
+    const int csteps = (C + 1) >> 1;
+    const long long step = 2LL * n;
+    const bool odd_c = (C & 1) != 0;
+    float xa[2][U], x0[2][U], x1[2][U];
+    auto load_block = [&](int set, int cp0) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) acc[d] = 0.0f;
-
-    for (int c0 = 0; c0 < C; c0 += kChunk) {
-        const int cc = min(kChunk, C - c0);
-        __syncthreads();
-        for (int e = threadIdx.x; e < cc * W1; e += kTile * kGroups) {
-            const int c = e / W1, x = e - c * W1;
-            const int src = min(max(i0 - HK + x, 0), n - 1);
-            s1[c][x] = g1[(long long)(c0 + c) * n + src];
+        for (int u = 0; u < U; ++u) {
+            const int cp = min(cp0 + u, csteps - 1);
+            // the upper half-wave of an odd last step would read channel C: it re-reads C-1 (zeroed below)
+            const int ho = (odd_c && cp == csteps - 1) ? 0 : hoff;
+            const float *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
+            xa[set][u] = r1[la + ho];
+            x0[set][u] = r2[l0 + ho];
+            x1[set][u] = r2[l1 + ho];
         }
-        for (int e = threadIdx.x; e < cc * W2; e += kTile * kGroups) {
-            const int c = e / W2, y = e - c * W2;
-            const int src = min(max(i0 - MD - HK + y, 0), n - 1);
-            s2[c][y] = g2[(long long)(c0 + c) * n + src];
+    };
+    auto mac_block = [&](int set, int cp0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cp = cp0 + u;
+            const bool ok = cp < csteps && !(odd_c && cp == csteps - 1 && h == 1);
+            const float a = (va && ok) ? xa[set][u] : 0.0f;
+            const float b0 = (vb0 && ok) ? x0[set][u] : 0.0f;
+            const float b1 = (vb1 && ok) ? x1[set][u] : 0.0f;
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
         }
-        __syncthreads();
-        if (i < n) {
-            for (int c = grp; c < cc; c += kGroups) {
-                float p1[K];
-#pragma unroll
-                for (int k = 0; k < K; ++k) p1[k] = s1[c][lane + k];
-                if (interior) {
-                    float w[D + K - 1];
-#pragma unroll
-                    for (int y = 0; y < D + K - 1; ++y) w[y] = s2[c][lane + y];
-#pragma unroll
-                    for (int d = 0; d < D; ++d)
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[d] = fmaf(p1[k], w[d + k], acc[d]);
-                } else {
-#pragma unroll
-                    for (int d = 0; d < D; ++d) {
-                        const int j = min(max(i + d - MD, 0), n - 1);
-                        const int base = j - (i0 - MD - HK) - HK;  // staged position of j-HK
-#pragma unroll
-                        for (int k = 0; k < K; ++k) acc[d] = fmaf(p1[k], s2[c][base + k], acc[d]);
-                    }
-                }
-            }
+    };
+    load_block(0, 0);
+    for (int cp0 = 0; cp0 < csteps; cp0 += 2 * U) {
+        load_block(1, cp0 + U);
+        mac_block(0, cp0);
+        if (cp0 + U < csteps) {
+            load_block(0, cp0 + 2 * U);
+            mac_block(1, cp0 + U);
         }
     }
+    // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    float *P = s_p[wave];
 #pragma unroll
-    for (int d = 0; d < D; ++d) s_red[grp][d][lane] = acc[d];
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+        P[row * kPld + r] = acc0[reg];
+        P[row * kPld + 32 + r] = acc1[reg];
+    }
     __syncthreads();
-    for (int e = threadIdx.x; e < D * kTile; e += kTile * kGroups) {
-        const int d = e / kTile, l = e - d * kTile;
-        if (i0 + l < n) {
-            float v = s_red[0][d][l];
+    float *o = out + (long long)b * D * n;
+    for (int e = lane; e < D * PTS; e += 64) {
+        const int d = e / PTS, il = e - d * PTS;
+        const int i = i0 + il;
+        if (i >= n || !live) continue;
+        const int j = min(max(i + d - MD, 0), n - 1);
+        float v = 0.0f;
 #pragma unroll
-            for (int g = 1; g < kGroups; ++g) v += s_red[g][d][l];
-            out[((long long)b * D + d) * n + i0 + l] = v;
+        for (int k = 0; k < K; ++k) {
+            const int row = min(max(i + k - HK, 0), n - 1) - ra;
+            const int col = min(max(j + k - HK, 0), n - 1) - cb;
+            v += P[row * kPld + col];
         }
+        o[(long long)d * n + i] = v;
+    }
+}
+
+// n <= 64: the whole 64 x 64 Gram block of one sample in ONE wave.  Lane (r, h) loads the
+// position pair (2r, 2r+1) of channel c+h with one 8-byte load per operand; the even and odd
+// positions form two 32-row (32-column) MFMA operands, so each channel pair costs 2 loads and
+// 4 MFMAs, every element of the sample is read exactly once, and P[row][col] is complete for
+// any kernel size / displacement (all clamped indices lie in [0, n)).
+constexpr int kSmallWaves = 4;
+constexpr int kBandLd = 2 * (kMaxD / 2 + 2 * (kMaxK / 2)) + 2;   // 2 * 11 + 2: widest band, even stride
+
+template <int K>
+__global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const float *f1, const float *f2,
+                                                                           float *out, int B, int C, int n, int D)
+{
+    constexpr int HK = K / 2;
+    __shared__ float s_p[kSmallWaves][64 * kBandLd];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b_raw = blockIdx.x * kSmallWaves + wave;
+    const bool live = b_raw < B;
+    const int b = live ? b_raw : B - 1;
+    const int MD = D / 2;
+    const int r = lane & 31, h = lane >> 5;
+    const float *g1 = f1 + (long long)b * C * n;
+    const float *g2 = f2 + (long long)b * C * n;
+    // pair start clamped into the row; which half of the loaded pair is the even position
+    const int p = max(min(2 * r, n - 2), 0);
+    const bool ve = 2 * r < n, vo = 2 * r + 1 < n;
+    const bool even_is_y = ve && (2 * r != p);       // odd n, last position: the pair is (n-2, n-1)
+    const int hoff = h * n;
+
+    f32x16 acc_ee = {0}, acc_eo = {0}, acc_oe = {0}, acc_oo = {0};
+    constexpr int U = 8;
+    const int csteps = (C + 1) >> 1;
+    const long long step = 2LL * n;
+    const bool odd_c = (C & 1) != 0;
+    using F2 = float __attribute__((ext_vector_type(2)));
+    F2 xa[2][U], xb[2][U];
+    auto load_block = [&](int set, int cp0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cp = min(cp0 + u, csteps - 1);
+            const int ho = (odd_c && cp == csteps - 1) ? 0 : hoff;
+            const float *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
+            // 4-byte aligned 8-byte loads (odd rows of an odd-n tensor start on a 4-byte boundary)
+            __builtin_memcpy(&xa[set][u], r1 + p + ho, 8);
+            __builtin_memcpy(&xb[set][u], r2 + p + ho, 8);
+        }
+    };
+    auto mac_block = [&](int set, int cp0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int cp = cp0 + u;
+            const bool ok = cp < csteps && !(odd_c && cp == csteps - 1 && h == 1);
+            const F2 a = xa[set][u], bb = xb[set][u];
+            const float ae = (ve && ok) ? (even_is_y ? a.y : a.x) : 0.0f;
+            const float ao = (vo && ok) ? a.y : 0.0f;
+            const float be = (ve && ok) ? (even_is_y ? bb.y : bb.x) : 0.0f;
+            const float bo = (vo && ok) ? bb.y : 0.0f;
+            acc_ee = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, be, acc_ee, 0, 0, 0);
+            acc_eo = __builtin_amdgcn_mfma_f32_32x32x2f32(ae, bo, acc_eo, 0, 0, 0);
+            acc_oe = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, be, acc_oe, 0, 0, 0);
+            acc_oo = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, bo, acc_oo, 0, 0, 0);
+        }
+    };
+    load_block(0, 0);
+    for (int cp0 = 0; cp0 < csteps; cp0 += 2 * U) {
+        load_block(1, cp0 + U);
+        mac_block(0, cp0);
+        if (cp0 + U < csteps) {
+            load_block(0, cp0 + 2 * U);
+            mac_block(1, cp0 + U);
+        }
+    }
+    // Only the band |col - row| <= MD + 2*HK is ever read: keep P[row][col - row + HB] (HB-centred,
+    // kBandLd wide) instead of the full 64 x 64 block -- 4 KB per wave, so LDS does not limit occupancy.
+    // tile (pr, pc): row = 2 * rowidx + pr, col = 2 * r + pc, rowidx from the C/D layout
+    float *P = s_p[wave];
+    const int HB = MD + 2 * HK;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+        const int row = 2 * ((reg & 3) + 8 * (reg >> 2) + 4 * h);
+        const int c0 = 2 * r - row + HB;        // band slot of (row, 2r)
+        if (c0 >= 0 && c0 < kBandLd) P[row * kBandLd + c0] = acc_ee[reg];
+        if (c0 + 1 >= 0 && c0 + 1 < kBandLd) P[row * kBandLd + c0 + 1] = acc_eo[reg];
+        if (c0 - 1 >= 0 && c0 - 1 < kBandLd) P[(row + 1) * kBandLd + c0 - 1] = acc_oe[reg];
+        if (c0 >= 0 && c0 < kBandLd) P[(row + 1) * kBandLd + c0] = acc_oo[reg];
+    }
+    __syncthreads();
+    float *o = out + (long long)b * D * n;
+    for (int e = lane; e < D * n; e += 64) {
+        const int d = e / n, i = e - d * n;
+        if (!live) continue;
+        const int j = min(max(i + d - MD, 0), n - 1);
+        float v = 0.0f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int row = min(max(i + k - HK, 0), n - 1);
+            const int col = min(max(j + k - HK, 0), n - 1);
+            v += P[row * kBandLd + col - row + HB];
+        }
+        o[e] = v;
     }
 }
 
@@ -145,21 +279,18 @@ __global__ __launch_bounds__(256) void band_corr_bwd_kernel(const float *f1, con
 }
 
 template <int K>
-int launch_k(const float *f1, const float *f2, float *out, int B, int C, int n, int D, hipStream_t s)
+void launch_k(const float *f1, const float *f2, float *out, int B, int C, int n, int D, hipStream_t s)
 {
-    dim3 grid((n + kTile - 1) / kTile, B), block(kTile * kGroups);
-    switch (D) {
-        case 1: band_corr_kernel<K, 1><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 3: band_corr_kernel<K, 3><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 5: band_corr_kernel<K, 5><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 7: band_corr_kernel<K, 7><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 9: band_corr_kernel<K, 9><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 11: band_corr_kernel<K, 11><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 13: band_corr_kernel<K, 13><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        case 15: band_corr_kernel<K, 15><<<grid, block, 0, s>>>(f1, f2, out, C, n); break;
-        default: return POF_E_SHAPE;
+    if (n >= 2 && n <= 64) {
+        band_corr_small_kernel<K><<<(B + kSmallWaves - 1) / kSmallWaves, 64 * kSmallWaves, 0, s>>>(f1, f2, out, B, C,
+                                                                                                n, D);
+        return;
     }
-    return POF_OK;
+    constexpr int PTS = 32 - (K - 1);
+    const int nblk = (n + PTS - 1) / PTS;
+    const long long units = (long long)B * nblk;
+    const unsigned grid = (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);
+    band_corr_kernel<K><<<grid, 64 * kWavesPerBlock, 0, s>>>(f1, f2, out, B, C, n, D, nblk);
 }
 
 }  // namespace
@@ -175,13 +306,11 @@ extern "C" int pof_band_correlation(const float *feat1, const float *feat2, floa
     if (B > 65535) return POF_E_SHAPE;
     const int D = 2 * max_disp + 1;
     hipStream_t s = pof_stream(stream);
-    int rc;
     switch (kernel_size) {
-        case 1: rc = launch_k<1>(feat1, feat2, out, B, C, n, D, s); break;
-        case 3: rc = launch_k<3>(feat1, feat2, out, B, C, n, D, s); break;
-        default: rc = launch_k<5>(feat1, feat2, out, B, C, n, D, s); break;
+        case 1: launch_k<1>(feat1, feat2, out, B, C, n, D, s); break;
+        case 3: launch_k<3>(feat1, feat2, out, B, C, n, D, s); break;
+        default: launch_k<5>(feat1, feat2, out, B, C, n, D, s); break;
     }
-    if (rc != POF_OK) return rc;
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

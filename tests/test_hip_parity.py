@@ -322,6 +322,20 @@ def test_band_correlation_wide(ops):
                                rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("n", [2, 5, 31, 57, 63, 64, 65, 70, 128, 451])
+def test_band_correlation_shapes(ops, n):
+    """Both MFMA forms (one wave per sample for n <= 64, 30-point blocks beyond), odd channel
+    counts, every kernel size, displacement 0..7, integer data so that float32 sums are exact."""
+    rng = np.random.default_rng(100 + n)
+    for C, K, md in [(1, 1, 0), (3, 3, 2), (16, 5, 7), (37, 3, 5), (64, 1, 7), (33, 5, 0)]:
+        f1 = rng.integers(-4, 5, (3, C, n)).astype(np.float32)
+        f2 = rng.integers(-4, 5, (3, C, n)).astype(np.float32)
+        out = ops.band_correlation(T(f1), T(f2), K, md).cpu().numpy()
+        ref = R.band_correlation(f1.astype(np.float64), f2.astype(np.float64), K, md)
+        assert out.shape == ref.shape
+        assert np.array_equal(out, ref.astype(np.float32)), (n, C, K, md, np.abs(out - ref).max())
+
+
 # ---------------------------------------------------------------- A10
 @pytest.mark.parametrize("name,alpha,w", [("spatial_attn", 0.5, 11), ("spatial_attn_w7", 0.3, 7)])
 def test_spatial_attention_golden(ops, golden, name, alpha, w):
