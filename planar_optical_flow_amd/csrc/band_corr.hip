@@ -231,50 +231,115 @@ __global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const
     }
 }
 
-// Backward: scatter form.  Each lane owns (channel, point i) and adds its
-// contributions to d_f1[c, clamp(i+k-hk)] and d_f2[c, clamp(j_d+k-hk)] in LDS
-// (ds_add_f32), the tile is then written out.  One workgroup = one sample x
-// kBwdCh channels x all n points (n <= kBwdMaxN).
-constexpr int kBwdCh = 8;
+// Backward on the float32 MFMA.  With G[a][b] = dL/dP[a][b] (the output gradient scattered
+// back onto the band of the Gram matrix, |b - a| <= HB = md + 2*hk):
+//     d_f1[c][a] = sum_b f2[c][b] * G[a][b]          d_f2[c][b] = sum_a f1[c][a] * G[a][b]
+// -- two [32 channels] x [32 positions] MFMA tiles per unit, contracted over the <= 32 + 2*HB
+// positions of the band window.  The contraction runs over the contiguous axis of f, so the
+// lanes of the A operand run along channels: lane (r, h) loads the 16 bytes
+// f[c0 + r][q + 4h .. q + 4h + 3] (4 contraction steps per load; the k order inside an MFMA is
+// free as long as both operands agree), the B operand is read from the band image of G in LDS.
+//
+// Phase 1 builds G deterministically (gather form: every band entry sums its contributions in a
+// fixed order; no LDS atomics).  One workgroup = one sample; its 4 waves share G and split the
+// (channel chunk, position block, which gradient) tiles.
 constexpr int kBwdMaxN = 512;
+constexpr int kBwdWaves = 4;
 
-__global__ __launch_bounds__(256) void band_corr_bwd_kernel(const float *f1, const float *f2,
-                                                            const float *g_out, float *d_f1, float *d_f2,
-                                                            int C, int n, int K, int D)
+template <int K>
+__global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const float *f1, const float *f2,
+                                                                      const float *g_out, float *d_f1, float *d_f2,
+                                                                      int C, int n, int D)
 {
-    extern __shared__ float smem_f[];
-    float *s_g = smem_f;                 // [D][n]
-    float *s_d1 = s_g + D * n;           // [kBwdCh][n]
-    float *s_d2 = s_d1 + kBwdCh * n;     // [kBwdCh][n]
-    const int b = blockIdx.y, c0 = blockIdx.x * kBwdCh;
-    const int cc = min(kBwdCh, C - c0);
-    const int hk = K / 2, md = D / 2;
-    for (int e = threadIdx.x; e < D * n; e += blockDim.x) s_g[e] = g_out[(long long)b * D * n + e];
-    for (int e = threadIdx.x; e < 2 * kBwdCh * n; e += blockDim.x) s_d1[e] = 0.0f;
+    constexpr int HK = K / 2;
+    extern __shared__ float s_g[];               // [n][W]: G[a][a - HB + s], then [D][n]: the output gradient
+    const int MD = D / 2, HB = MD + 2 * HK, W = 2 * HB + 1;
+    const int b = blockIdx.x;
+    float *go = s_g + n * W;
+    for (int e = threadIdx.x; e < D * n; e += 64 * kBwdWaves) go[e] = g_out[(long long)b * D * n + e];
     __syncthreads();
-    const float *g1 = f1 + ((long long)b * C + c0) * n;
-    const float *g2 = f2 + ((long long)b * C + c0) * n;
-    for (int e = threadIdx.x; e < cc * n; e += blockDim.x) {
-        const int c = e / n, i = e - c * n;
-        const float *r1 = g1 + (long long)c * n, *r2 = g2 + (long long)c * n;
-        for (int k = 0; k < K; ++k) {
-            const int a1 = min(max(i + k - hk, 0), n - 1);
-            const float v1 = r1[a1];
-            float acc1 = 0.0f;
-            for (int d = 0; d < D; ++d) {
-                const int j = min(max(i + d - md, 0), n - 1);
-                const int a2 = min(max(j + k - hk, 0), n - 1);
-                const float gv = s_g[d * n + i];
-                acc1 = fmaf(gv, r2[a2], acc1);
-                atomicAdd(&s_d2[c * n + a2], gv * v1);
+
+    // ---- phase 1: G[a][bb] = sum over (k, i, d) with A(i,k) = a and Bc(i,d,k) = bb of g[d][i] ----
+    for (int e = threadIdx.x; e < n * W; e += 64 * kBwdWaves) {
+        const int a = e / W, s = e - a * W;
+        const int bb = a - HB + s;
+        float acc = 0.0f;
+        if (bb >= 0 && bb < n) {
+            for (int k = 0; k < K; ++k) {
+                // i with clamp(i + k - HK) == a: a single i in the interior, a run at either end
+                int i_lo = a - k + HK, i_hi = i_lo;
+                if (a == 0) i_lo = 0;
+                if (a == n - 1) i_hi = n - 1;
+                i_lo = max(i_lo, 0);
+                i_hi = min(i_hi, n - 1);
+                for (int i = i_lo; i <= i_hi; ++i) {
+                    if (min(max(i + k - HK, 0), n - 1) != a) continue;
+                    for (int d = 0; d < D; ++d) {
+                        const int j = min(max(i + d - MD, 0), n - 1);
+                        if (min(max(j + k - HK, 0), n - 1) == bb) acc += go[d * n + i];
+                    }
+                }
             }
-            atomicAdd(&s_d1[c * n + a1], acc1);
         }
+        s_g[e] = acc;
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < cc * n; e += blockDim.x) {
-        d_f1[((long long)b * C + c0) * n + e] = s_d1[e];
-        d_f2[((long long)b * C + c0) * n + e] = s_d2[e];
+
+    // ---- phase 2: MFMA tiles -----------------------------------------------------------------
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int nchunk = (C + 31) >> 5, nblk = (n + 31) >> 5;
+    const int units = nchunk * nblk * 2;
+    auto band = [&](int a, int bb) -> float {   // G[a][bb], zero outside the band / the scan
+        const int s = bb - a + HB;
+        return (a >= 0 && a < n && bb >= 0 && bb < n && s >= 0 && s < W) ? s_g[a * W + s] : 0.0f;
+    };
+    for (int u = wave; u < units; u += kBwdWaves) {
+        const int which = u & 1;                 // 0: d_f1 (reads f2), 1: d_f2 (reads f1)
+        const int blk = (u >> 1) % nblk, chunk = (u >> 1) / nblk;
+        const int c0 = chunk * 32, p0 = blk * 32;
+        const float *src = (which == 0 ? f2 : f1) + (long long)b * C * n;
+        float *dst = (which == 0 ? d_f1 : d_f2) + (long long)b * C * n;
+        const int crow = min(c0 + r, C - 1);     // clamped row keeps masked lanes' loads in bounds
+        const bool cvalid = c0 + r < C;
+        const float *row = src + (long long)crow * n;
+        const int w0 = max(p0 - HB, 0), w1 = min(p0 + 31 + HB, n - 1);
+        f32x16 acc = {0};
+        // all loads of the tile first (<= 8 groups of 8 positions: 32 + 2 * 11 + 7 < 64), then the MFMAs
+        constexpr int kMaxQ = 8;
+        float x[kMaxQ][4];
+#pragma unroll
+        for (int qi = 0; qi < kMaxQ; ++qi) {
+            const int q = w0 + 8 * qi;
+            const int pos0 = q + 4 * h;
+            if (q <= w1) {
+                if (q + 7 <= n - 1) {            // uniform: the whole 8-position group is inside the row
+                    __builtin_memcpy(x[qi], row + pos0, 16);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) x[qi][t] = row[min(pos0 + t, n - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int qi = 0; qi < kMaxQ; ++qi) {
+            const int q = w0 + 8 * qi;
+            if (q > w1) break;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int pos = q + 4 * h + t;
+                const float av = (cvalid && pos < n) ? x[qi][t] : 0.0f;
+                const float bv = which == 0 ? band(p0 + r, pos) : band(pos, p0 + r);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+            }
+        }
+        // C/D layout: col = lane & 31 (position), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (channel)
+        const int pcol = p0 + r;
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int c = c0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            if (c < C && pcol < n) dst[(long long)c * n + pcol] = acc[reg];
+        }
     }
 }
 
@@ -327,9 +392,21 @@ extern "C" int pof_band_correlation_backward(const float *feat1, const float *fe
     if (B == 0) return POF_OK;
     if (B > 65535) return POF_E_SHAPE;
     const int D = 2 * max_disp + 1;
-    const size_t lds = (size_t)(D + 2 * kBwdCh) * n * sizeof(float);
-    band_corr_bwd_kernel<<<dim3((C + kBwdCh - 1) / kBwdCh, B), 256, lds, pof_stream(stream)>>>(
-        feat1, feat2, g_out, d_feat1, d_feat2, C, n, kernel_size, D);
+    const int W = 2 * (max_disp + 2 * (kernel_size / 2)) + 1;
+    const size_t lds = (size_t)n * (W + D) * sizeof(float);     // <= 512 * (23 + 15) * 4 = 78 KB
+    if (lds > 64 * 1024) {
+        const void *fn = kernel_size == 1 ? reinterpret_cast<const void *>(band_corr_bwd_kernel<1>)
+                         : kernel_size == 3 ? reinterpret_cast<const void *>(band_corr_bwd_kernel<3>)
+                                            : reinterpret_cast<const void *>(band_corr_bwd_kernel<5>);
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return POF_E_LAUNCH;
+    }
+    hipStream_t s = pof_stream(stream);
+    switch (kernel_size) {
+        case 1: band_corr_bwd_kernel<1><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D); break;
+        case 3: band_corr_bwd_kernel<3><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D); break;
+        default: band_corr_bwd_kernel<5><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D); break;
+    }
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

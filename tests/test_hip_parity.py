@@ -481,6 +481,21 @@ def test_band_correlation_backward_vs_autograd(ops):
         np.testing.assert_allclose(g2.cpu().numpy(), f2.grad.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("n", [1, 5, 57, 64, 65, 130])
+def test_band_correlation_backward_shapes(ops, n):
+    """MFMA backward against torch autograd of the reference formulation on integer data (all sums
+    exact in float32): odd channel counts, every kernel size, displacement 0..7."""
+    gen = torch.Generator(device="cpu").manual_seed(200 + n)
+    for C, K, md in [(1, 1, 0), (3, 3, 2), (33, 5, 7), (40, 3, 5), (64, 1, 7)]:
+        f1 = torch.randint(-3, 4, (2, C, n), generator=gen).float().to(DEV).requires_grad_(True)
+        f2 = torch.randint(-3, 4, (2, C, n), generator=gen).float().to(DEV).requires_grad_(True)
+        gout = torch.randint(-3, 4, (2, 2 * md + 1, n), generator=gen).float().to(DEV)
+        (_torch_fusion(f1, f2, K, md) * gout).sum().backward()
+        d1, d2 = ops.band_correlation_backward(f1.detach(), f2.detach(), gout, K, md)
+        assert torch.equal(d1, f1.grad), (n, C, K, md, (d1 - f1.grad).abs().max().item())
+        assert torch.equal(d2, f2.grad), (n, C, K, md, (d2 - f2.grad).abs().max().item())
+
+
 def test_spatial_attention_backward_vs_autograd(ops):
     import sys, os
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd"))

@@ -56,3 +56,22 @@ if "corr" in which:
         ms = timeit(lambda: ops.band_correlation(f1, f2, 3, 5, out=out), iters=10)
         byt = B * (2 * C * n * 4 + 11 * n * 4)
         print("corr B=%d C=%d n=%d: %.3f ms  %.0f GB/s  %.1f TFLOP/s" % (B, C, n, ms, byt / ms / 1e6, B * 2 * 11 * n * 3 * C / ms / 1e9))
+if "bwd" in which:
+    for (B, C, n) in [(4096, 256, 57)]:
+        f1 = torch.randn((B, C, n), device=dev); f2 = torch.randn((B, C, n), device=dev)
+        g = torch.randn((B, 11, n), device=dev)
+        ms = timeit(lambda: ops.band_correlation_backward(f1, f2, g, 3, 5), iters=10)
+        byt = B * (4 * C * n * 4 + 11 * n * 4)
+        print("corr backward B=%d C=%d n=%d: %.3f ms  %.0f GB/s" % (B, C, n, ms, byt / ms / 1e6))
+    for B in (64,):
+        N, E, F = 450, 128, 3584
+        gen = torch.Generator(device=dev).manual_seed(10)
+        ex = torch.randn((B, N, E), device=dev, generator=gen) * 0.3
+        et = torch.randn((B, N, E), device=dev, generator=gen) * 0.3
+        x = torch.randn((B, N, F), device=dev, generator=gen)
+        t = torch.randn((B, N, F), device=dev, generator=gen)
+        out, band, prob = ops.spatial_attention(ex, et, x, t, 0.5, 11)
+        go = torch.randn_like(out); gb = torch.randn_like(band)
+        ms = timeit(lambda: ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, 11), iters=10)
+        per = 4 * N * F * 4 + 4 * N * E * 4 + 3 * N * 11 * 4     # read g, tmpl; write dx, dtmpl; emb in/out
+        print("attn backward B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
