@@ -250,41 +250,99 @@ int dispatch_merge(int W, const float *x, const float *tmpl, const float *prob, 
 }
 
 // ---- backward --------------------------------------------------------------------
-// One wave per point i: dp[k] = (1-alpha) <g[i], tmpl[i-HW+k]> over F (distinct columns
-// only), softmax backward ds = p (dp - sum p dp), dsim = ds + g_band -> dsim[b,i,k].
-__global__ __launch_bounds__(256) void attn_dsim_kernel(const float4 *g_out, const float4 *tmpl,
-                                                        const float *prob, const float *g_band, int N,
-                                                        int F4, int W, float one_minus_alpha, float *dsim)
+// One wave per 16 consecutive points: dp[i][k] = (1-alpha) <g[i], tmpl[i-hw+k]> is the band of the
+// 16 x 32 block  P = G_rows x Tmpl_rows^T  (rows i0..i0+15 against rows i0-hw..i0-hw+31), contracted
+// over F on the float32 MFMA (v_mfma_f32_16x16x4_f32; lane (r, q) holds row r, k = q).  F is the
+// contiguous axis, so every lane loads 16 bytes of its row per 16-float step and the four MFMAs of
+// the step take elements 0..3 (both operands use the same permuted k order); 4 lanes cover 64
+// contiguous bytes of a row.  Steps are register double-buffered in blocks of kDsU.  The epilogue
+// drops the block into LDS and 16 lanes run the softmax backward of their row:
+//   ds = p * (dp - sum_k p dp),  dsim = ds + g_band.
+constexpr int kDsWaves = 4;
+constexpr int kDsU = 4;
+using f32x4 = float __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(64 * kDsWaves) void attn_dsim_kernel(const float *g_out, const float *tmpl,
+                                                                 const float *prob, const float *g_band, int B, int N,
+                                                                 int F, int W, float one_minus_alpha, float *dsim)
 {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (i >= N) return;
-    const int hw = W / 2;
-    const float4 *g = g_out + ((long long)b * N + i) * F4;
-    const float4 *T = tmpl + (long long)b * N * F4;
-    float mine = 0.0f;
-    for (int k = 0; k < W; ++k) {
-        const int j = i - hw + k;
-        float part = 0.0f;
-        if (j >= 0 && j <= N - 1) {
-            const float4 *tj = T + (long long)j * F4;
-            for (int c = lane; c < F4; c += 64) {
-                const float4 a = g[c], t = tj[c];
-                part = fmaf(a.x, t.x, part);
-                part = fmaf(a.y, t.y, part);
-                part = fmaf(a.z, t.z, part);
-                part = fmaf(a.w, t.w, part);
+    __shared__ float s_p[kDsWaves][16 * 33];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int nblk = (N + 15) >> 4;
+    const int unit_raw = blockIdx.x * kDsWaves + wave;
+    const bool live = unit_raw < B * nblk;
+    const int unit = live ? unit_raw : B * nblk - 1;   // tail waves recompute the last unit, store nothing
+    const int b = unit / nblk, i0 = (unit - b * nblk) * 16;
+    const int hw = W / 2, cb = i0 - hw;
+    const int r = lane & 15, q = lane >> 4;
+    const int ri = i0 + r, j0 = cb + r, j1 = cb + 16 + r;
+    const bool vi = ri < N, v0 = j0 >= 0 && j0 < N, v1 = j1 >= 0 && j1 < N;
+    const float *base_g = g_out + (long long)b * N * F;
+    const float *base_t = tmpl + (long long)b * N * F;
+    // per-lane element offsets (rows clamped so that masked lanes still load inside the sample)
+    const long long og = (long long)min(ri, N - 1) * F + 4 * q;
+    const long long o0 = (long long)min(max(j0, 0), N - 1) * F + 4 * q;
+    const long long o1 = (long long)min(max(j1, 0), N - 1) * F + 4 * q;
+    const int steps = (F + 15) >> 4;
+
+    f32x4 acc0 = {0}, acc1 = {0};
+    f32x4 xg[2][kDsU], x0[2][kDsU], x1[2][kDsU];
+    auto load_block = [&](int set, int s0) {
+#pragma unroll
+        for (int u = 0; u < kDsU; ++u) {
+            // a step past the end, or the last lanes of a partial step, re-read the row's last 16 bytes
+            const int f = min(16 * min(s0 + u, steps - 1) + 4 * q, F - 4) - 4 * q;
+            xg[set][u] = *reinterpret_cast<const f32x4 *>(base_g + og + f);
+            x0[set][u] = *reinterpret_cast<const f32x4 *>(base_t + o0 + f);
+            x1[set][u] = *reinterpret_cast<const f32x4 *>(base_t + o1 + f);
+        }
+    };
+    auto mac_block = [&](int set, int s0) {
+#pragma unroll
+        for (int u = 0; u < kDsU; ++u) {
+            const bool ok = (s0 + u < steps) && (16 * (s0 + u) + 4 * q < F);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float a = (vi && ok) ? xg[set][u][t] : 0.0f;
+                const float b0 = (v0 && ok) ? x0[set][u][t] : 0.0f;
+                const float b1 = (v1 && ok) ? x1[set][u][t] : 0.0f;
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
             }
         }
-        part = wave_sum_f32(part);
-        if (lane == k) mine = part * one_minus_alpha;
+    };
+    load_block(0, 0);
+    for (int s0 = 0; s0 < steps; s0 += 2 * kDsU) {
+        load_block(1, s0 + kDsU);
+        mac_block(0, s0);
+        if (s0 + kDsU < steps) {
+            load_block(0, s0 + 2 * kDsU);
+            mac_block(1, s0 + kDsU);
+        }
     }
-    const bool slot = lane < W;
-    const long long o = ((long long)b * N + i) * W + lane;
-    const float p = slot ? prob[o] : 0.0f;
-    const float s = wave_sum_f32(p * mine);
-    if (slot) dsim[o] = p * (mine - s) + (g_band ? g_band[o] : 0.0f);
+    // C/D layout (16x16): col = lane & 15, row = 4 * (lane >> 4) + reg
+    float *P = s_p[wave];
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+        P[(4 * q + reg) * 33 + r] = acc0[reg];
+        P[(4 * q + reg) * 33 + 16 + r] = acc1[reg];
+    }
+    __syncthreads();
+    if (lane < 16 && live && i0 + lane < N) {
+        const int i = i0 + lane;
+        const long long o = ((long long)b * N + i) * W;
+        float s = 0.0f;
+        for (int k = 0; k < W; ++k) {
+            const int j = i - hw + k;   // unclamped column: out-of-range slots carry no weight
+            const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
+            s = fmaf(prob[o + k], dp, s);
+        }
+        for (int k = 0; k < W; ++k) {
+            const int j = i - hw + k;
+            const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
+            dsim[o + k] = prob[o + k] * (dp - s) + (g_band ? g_band[o + k] : 0.0f);
+        }
+    }
 }
 
 // d emb_x[i] = sum_k dsim[i,k] emb_t[clamp(i-hw+k)]
@@ -307,12 +365,16 @@ __global__ __launch_bounds__(256) void attn_demb_kernel(const float *emb_x, cons
             const int j = min(max(r - hw + k, 0), N - 1);
             ax = fmaf(ds[(long long)r * W + k], et[(long long)j * E + e], ax);
         }
-        // rows whose window reaches column r (r plays the role of j)
+        // rows whose window reaches column r (r plays the role of j): clamp(i-hw+k) == r has the single
+        // solution k = r-i+hw for an interior r and a run of k at the two ends of the scan
         for (int i = max(r - hw, 0); i <= min(r + hw, N - 1); ++i) {
-            for (int k = 0; k < W; ++k) {
-                const int j = min(max(i - hw + k, 0), N - 1);
-                if (j == r) at = fmaf(ds[(long long)i * W + k], ex[(long long)i * E + e], at);
-            }
+            int k_lo = r - i + hw, k_hi = k_lo;
+            if (r == 0) k_lo = 0;
+            if (r == N - 1) k_hi = W - 1;
+            k_lo = max(k_lo, 0);
+            k_hi = min(k_hi, W - 1);
+            const float xv = ex[(long long)i * E + e];
+            for (int k = k_lo; k <= k_hi; ++k) at = fmaf(ds[(long long)i * W + k], xv, at);
         }
         d_emb_x[((long long)b * N + r) * E + e] = ax;
         d_emb_t[((long long)b * N + r) * E + e] = at;
@@ -371,9 +433,11 @@ extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *e
     if (B == 0) return POF_OK;
     if (B > 65535) return POF_E_SHAPE;
     hipStream_t s = pof_stream(stream);
-    attn_dsim_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(reinterpret_cast<const float4 *>(g_out),
-                                                          reinterpret_cast<const float4 *>(tmpl), prob, g_band,
-                                                          N, F / 4, W, (float)(1.0 - alpha), dsim);
+    {
+        const long long units = (long long)B * ((N + 15) / 16);
+        attn_dsim_kernel<<<(unsigned)((units + kDsWaves - 1) / kDsWaves), 64 * kDsWaves, 0, s>>>(
+            g_out, tmpl, prob, g_band, B, N, F, W, (float)(1.0 - alpha), dsim);
+    }
     POF_CHECK_LAUNCH();
     attn_demb_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, dsim, N, E, W, d_emb_x, d_emb_t);
     POF_CHECK_LAUNCH();
