@@ -262,9 +262,15 @@ constexpr int kDsWaves = 4;
 constexpr int kDsU = 4;
 using f32x4 = float __attribute__((ext_vector_type(4)));
 
+//
+// FWD = true is the forward similarity with the same structure (rows of emb_x against rows of emb_t,
+// contracted over E): band[i][k] = <emb_x[i], emb_t[clamp(i-hw+k)]> (clamped duplicates kept) and
+// the masked softmax over the distinct columns -> prob (written through `dsim`), band through `g_band_out`.
+template <bool FWD>
 __global__ __launch_bounds__(64 * kDsWaves) void attn_dsim_kernel(const float *g_out, const float *tmpl,
                                                                  const float *prob, const float *g_band, int B, int N,
-                                                                 int F, int W, float one_minus_alpha, float *dsim)
+                                                                 int F, int W, float one_minus_alpha, float *dsim,
+                                                                 float *band_out)
 {
     __shared__ float s_p[kDsWaves][16 * 33];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -331,16 +337,35 @@ __global__ __launch_bounds__(64 * kDsWaves) void attn_dsim_kernel(const float *g
     if (lane < 16 && live && i0 + lane < N) {
         const int i = i0 + lane;
         const long long o = ((long long)b * N + i) * W;
-        float s = 0.0f;
-        for (int k = 0; k < W; ++k) {
-            const int j = i - hw + k;   // unclamped column: out-of-range slots carry no weight
-            const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
-            s = fmaf(prob[o + k], dp, s);
-        }
-        for (int k = 0; k < W; ++k) {
-            const int j = i - hw + k;
-            const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
-            dsim[o + k] = prob[o + k] * (dp - s) + (g_band ? g_band[o + k] : 0.0f);
+        if (FWD) {
+            float mx = -INFINITY;
+            for (int k = 0; k < W; ++k) {
+                const int jc = min(max(i - hw + k, 0), N - 1);
+                mx = fmaxf(mx, P[lane * 33 + jc - cb]);
+            }
+            float sum = 0.0f;
+            for (int k = 0; k < W; ++k) {
+                const int ju = i - hw + k;  // unclamped column: clamped duplicates get no weight
+                if (ju >= 0 && ju <= N - 1) sum += expf(P[lane * 33 + ju - cb] - mx);
+            }
+            for (int k = 0; k < W; ++k) {
+                const int ju = i - hw + k;
+                const float sim = P[lane * 33 + min(max(ju, 0), N - 1) - cb];
+                if (band_out) band_out[o + k] = sim;
+                dsim[o + k] = (ju >= 0 && ju <= N - 1) ? expf(sim - mx) / sum : 0.0f;
+            }
+        } else {
+            float s = 0.0f;
+            for (int k = 0; k < W; ++k) {
+                const int j = i - hw + k;   // unclamped column: out-of-range slots carry no weight
+                const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
+                s = fmaf(prob[o + k], dp, s);
+            }
+            for (int k = 0; k < W; ++k) {
+                const int j = i - hw + k;
+                const float dp = (j >= 0 && j <= N - 1) ? P[lane * 33 + lane + k] * one_minus_alpha : 0.0f;
+                dsim[o + k] = prob[o + k] * (dp - s) + (g_band ? g_band[o + k] : 0.0f);
+            }
         }
     }
 }
@@ -399,16 +424,24 @@ extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, con
     if (B == 0) return POF_OK;
     if (B > 65535) return POF_E_SHAPE;
     hipStream_t s = pof_stream(stream);
-    if ((size_t)(2 * kBandTile + W - 1) * (E + 1) * sizeof(float) > 60 * 1024) return POF_E_SHAPE;  // E <= ~190
-    switch (W) {
-        case 1: launch_band<1>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 3: launch_band<3>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 5: launch_band<5>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 7: launch_band<7>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 9: launch_band<9>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 11: launch_band<11>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        case 13: launch_band<13>(emb_x, emb_t, B, N, E, band, prob, s); break;
-        default: launch_band<15>(emb_x, emb_t, B, N, E, band, prob, s); break;
+    if (E % 4 == 0) {
+        // banded emb_x . emb_t^T on the float32 MFMA (same kernel as the backward's g . tmpl^T)
+        const long long units = (long long)B * ((N + 15) / 16);
+        attn_dsim_kernel<true><<<(unsigned)((units + kDsWaves - 1) / kDsWaves), 64 * kDsWaves, 0, s>>>(
+            emb_x, emb_t, nullptr, nullptr, B, N, E, W, 0.0f, prob, band);
+    } else {
+        // embedding sizes that are not a multiple of 4 floats: LDS-tiled VALU form
+        if ((size_t)(2 * kBandTile + W - 1) * (E + 1) * sizeof(float) > 60 * 1024) return POF_E_SHAPE;
+        switch (W) {
+            case 1: launch_band<1>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 3: launch_band<3>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 5: launch_band<5>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 7: launch_band<7>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 9: launch_band<9>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 11: launch_band<11>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            case 13: launch_band<13>(emb_x, emb_t, B, N, E, band, prob, s); break;
+            default: launch_band<15>(emb_x, emb_t, B, N, E, band, prob, s); break;
+        }
     }
     POF_CHECK_LAUNCH();
     const int rc = dispatch_merge<false>(W, x, tmpl, prob, out, nullptr, B, N, F, alpha, s);
@@ -435,8 +468,8 @@ extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *e
     hipStream_t s = pof_stream(stream);
     {
         const long long units = (long long)B * ((N + 15) / 16);
-        attn_dsim_kernel<<<(unsigned)((units + kDsWaves - 1) / kDsWaves), 64 * kDsWaves, 0, s>>>(
-            g_out, tmpl, prob, g_band, B, N, F, W, (float)(1.0 - alpha), dsim);
+        attn_dsim_kernel<false><<<(unsigned)((units + kDsWaves - 1) / kDsWaves), 64 * kDsWaves, 0, s>>>(
+            g_out, tmpl, prob, g_band, B, N, F, W, (float)(1.0 - alpha), dsim, nullptr);
     }
     POF_CHECK_LAUNCH();
     attn_demb_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, dsim, N, E, W, d_emb_x, d_emb_t);

@@ -361,6 +361,25 @@ def test_spatial_attention_full_width(ops):
     np.testing.assert_allclose(out.cpu().numpy(), wo, rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("N,E,w", [(1, 4, 3), (5, 8, 11), (16, 20, 1), (17, 128, 15), (33, 36, 7),
+                                   (450, 128, 11), (40, 6, 5), (31, 13, 9)])
+def test_spatial_attention_band_shapes(ops, N, E, w):
+    """The band / softmax kernels (MFMA form for E % 4 == 0, LDS form otherwise) on small and odd
+    shapes: scans shorter than the window, one point, partial 16-point blocks, partial 16-float steps."""
+    rng = np.random.default_rng(N * 100 + E)
+    B, F = 3, 8
+    ex = rng.normal(0, 0.5, (B, N, E)).astype(np.float32)
+    et = rng.normal(0, 0.5, (B, N, E)).astype(np.float32)
+    x = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    t = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    out, band, prob = ops.spatial_attention(T(ex), T(et), T(x), T(t), 0.4, w)
+    wo, wb = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
+                                 t.astype(np.float64), 0.4, w)
+    np.testing.assert_allclose(band.cpu().numpy(), wb, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), wo, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(prob.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+
+
 # ---------------------------------------------------------------- A13
 def test_segment_features_vs_oracle(ops):
     sb = synth.make_batch(seed=13, B=4, T=1, dropout=0.0)
