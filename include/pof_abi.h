@@ -198,6 +198,14 @@ int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, in
                   double padding_val, int area_mode, int value_mode, float *out, int32_t *workspace,
                   int32_t *dbg_lo, pof_stream_t stream);
 
+/* BASELINE config 5 storage: the same cutout written as IEEE float16 (the float32 result
+ * rounded to nearest even once more), out_f16 [B][ceil(N/stride)][T][P] half.  Halves the
+ * dominant write traffic (3600*11*(4 + 56*2) bytes per dense sample). */
+int pof_cutout_f16(const float *scans, int B, int T, int N, const double *tab, int stride, int centered,
+                   int fixed, double window_width, double window_depth, int num_cutout_pts,
+                   double padding_val, int area_mode, int value_mode, void *out_f16, int32_t *workspace,
+                   int32_t *dbg_lo, pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A11 nms_predicted_center                      src/utils/utils.py:535-571
  * One scan per batch entry.  pred_cls [B][N] float64 scores, pred_reg [B][N][2].

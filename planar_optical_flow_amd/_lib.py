@@ -38,6 +38,7 @@ SIGNATURES = {
     "pof_canonical_to_det": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _p]),
     "pof_cutout": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _d, _d, _i, _d, _i, _p, _p, _p, _p]),
     "pof_cutout_ex": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _d, _d, _i, _d, _i, _i, _p, _p, _p, _p]),
+    "pof_cutout_f16": (_i, [_p, _i, _i, _i, _p, _i, _i, _i, _d, _d, _i, _d, _i, _i, _p, _p, _p, _p]),
     "pof_nms_workspace_bytes": (_sz, [_i, _i]),
     "pof_nms_predicted_center": (_i, [_p, _p, _p, _p, _d, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_flow_errors": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p]),

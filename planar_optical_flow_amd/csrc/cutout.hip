@@ -49,6 +49,7 @@ struct CutArgs {
     float padding_f32, rdepth_f32;
     double padding;
     float *out;
+    _Float16 *out16;    // config 5 storage: float16 output (same values, rounded once more); out is null then
     int32_t *s_area;
     int32_t *dbg_lo;
 };
@@ -297,7 +298,9 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     const int per_win = (P4 > 0) ? P4 : (P4 == 0 ? P / 4 : P);
     const int total = nwin * per_win;
     const double nm1 = (double)(N - 1);
-    float *out_tile = a.out + ((long long)b * a.Ns + j0) * T * P;
+    const long long tile_off = ((long long)b * a.Ns + j0) * T * P;
+    float *out_tile = a.out ? a.out + tile_off : nullptr;
+    _Float16 *out_tile16 = a.out16 ? a.out16 + tile_off : nullptr;
     const int tcount = a.fixed ? 1 : T;
 
     // One (window, 4-sample group): AREA = false is the interpolation path, AREA = true the
@@ -424,16 +427,32 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 y = fminf(fmaxf(y, ylo), yhi);
                 res[u] = outb[u] ? ypad : y;
             }
-            float *dst = out_tile + out_off + tt * P + k0;
-            if (KV >= 4) {
+            const int o_el = out_off + tt * P + k0;
+            if (out_tile16) {   // uniform: float16 storage, 2 bytes per sample (8 samples = one 16-byte store)
+                using H4 = _Float16 __attribute__((ext_vector_type(4)));
+                _Float16 *dst = out_tile16 + o_el;
+                if (KV >= 4) {
 #pragma unroll
-                // ordinary stores: the area list visits windows out of order, and partial-line
-                // streaming stores cost 2.3x on the fixed=False shape (L2 no longer merges them)
-                for (int v = 0; v < KV / 4; ++v)
-                    reinterpret_cast<float4 *>(dst)[v] =
-                        make_float4(res[(4 * v) % KV], res[(4 * v + 1) % KV], res[(4 * v + 2) % KV], res[(4 * v + 3) % KV]);
+                    for (int v = 0; v < KV / 4; ++v) {
+                        H4 hv = {(_Float16)res[(4 * v) % KV], (_Float16)res[(4 * v + 1) % KV],
+                                 (_Float16)res[(4 * v + 2) % KV], (_Float16)res[(4 * v + 3) % KV]};
+                        reinterpret_cast<H4 *>(dst)[v] = hv;
+                    }
+                } else {
+                    dst[0] = (_Float16)res[0];
+                }
             } else {
-                dst[0] = res[0];
+                float *dst = out_tile + o_el;
+                if (KV >= 4) {
+                    // ordinary stores: the area list visits windows out of order, and partial-line
+                    // streaming stores cost 2.3x on the fixed=False shape (L2 no longer merges them)
+#pragma unroll
+                    for (int v = 0; v < KV / 4; ++v)
+                        reinterpret_cast<float4 *>(dst)[v] =
+                            make_float4(res[(4 * v) % KV], res[(4 * v + 1) % KV], res[(4 * v + 2) % KV], res[(4 * v + 3) % KV]);
+                } else {
+                    dst[0] = res[0];
+                }
             }
         }
     };
@@ -481,12 +500,13 @@ void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool 
 
 }  // namespace
 
-extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, int stride,
-                             int centered, int fixed, double window_width, double window_depth,
-                             int num_cutout_pts, double padding_val, int area_mode, int value_mode,
-                             float *out, int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
+namespace {
+int cutout_launch(const float *scans, int B, int T, int N, const double *tab, int stride, int centered, int fixed,
+                  double window_width, double window_depth, int num_cutout_pts, double padding_val, int area_mode,
+                  int value_mode, float *out32, _Float16 *out16, int32_t *workspace, int32_t *dbg_lo,
+                  pof_stream_t stream)
 {
-    POF_CLEAR_STALE_ERROR();
+    void *out = out32 ? static_cast<void *>(out32) : static_cast<void *>(out16);
     if (value_mode < 0 || value_mode > 1) return POF_E_BADARG;
     if (!scans || !tab || !out || B < 0 || T < 1 || N < 2 || stride < 1 || num_cutout_pts < 2)
         return POF_E_BADARG;
@@ -511,7 +531,7 @@ extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const doub
     a.value_mode = value_mode;
     a.padding_f32 = (float)padding_val;
     a.rdepth_f32 = (float)(1.0 / window_depth);
-    a.out = out; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
+    a.out = out32; a.out16 = out16; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
         if (hipMemsetAsync(workspace, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return POF_E_LAUNCH;
@@ -535,12 +555,35 @@ extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const doub
     const bool span_mode = !rows_in_lds && a.span_cap >= 64;
     const size_t lds = tbl + (rows_in_lds ? row_bytes : (span_mode ? (size_t)a.span_cap * T * sizeof(float) : 0));
     dim3 grid((a.Ns + a.tile - 1) / a.tile, B);
+    // 16-byte float4 stores / 8-byte half4 stores both need P % 4 == 0 and an aligned base
     const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (rows_in_lds) launch_cutout<1>(a, grid, lds, s, vec4);
     else if (span_mode) launch_cutout<2>(a, grid, lds, s, vec4);
     else launch_cutout<0>(a, grid, lds, s, vec4);
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+}  // namespace
+
+extern "C" int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, int stride,
+                             int centered, int fixed, double window_width, double window_depth,
+                             int num_cutout_pts, double padding_val, int area_mode, int value_mode,
+                             float *out, int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return cutout_launch(scans, B, T, N, tab, stride, centered, fixed, window_width, window_depth, num_cutout_pts,
+                         padding_val, area_mode, value_mode, out, nullptr, workspace, dbg_lo, stream);
+}
+
+extern "C" int pof_cutout_f16(const float *scans, int B, int T, int N, const double *tab, int stride,
+                              int centered, int fixed, double window_width, double window_depth,
+                              int num_cutout_pts, double padding_val, int area_mode, int value_mode,
+                              void *out_f16, int32_t *workspace, int32_t *dbg_lo, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return cutout_launch(scans, B, T, N, tab, stride, centered, fixed, window_width, window_depth, num_cutout_pts,
+                         padding_val, area_mode, value_mode, nullptr, static_cast<_Float16 *>(out_f16), workspace,
+                         dbg_lo, stream);
 }
 
 extern "C" int pof_cutout(const float *scans, int B, int T, int N, const double *tab, int stride,

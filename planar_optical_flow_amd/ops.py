@@ -287,9 +287,12 @@ def canonical_to_det(ranges, tab, dx, dy):
 
 def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, window_depth=1.0,
            num_cutout_pts=48, padding_val=29.99, area_mode=False, out=None, return_debug=False,
-           exact_values=True):
+           exact_values=True, out_dtype=torch.float32):
     """A8 for a batch: scans [B,T,N] float32 -> [B, ceil(N/stride), T, P] float32.
-    exact_values=False selects the float32 value path (exact indices, values within 1e-5)."""
+    exact_values=False selects the float32 value path (exact indices, values within 1e-5);
+    out_dtype=torch.float16 stores the result as float16 (BASELINE config 5)."""
+    if out_dtype not in (torch.float32, torch.float16):
+        raise TypeError("out_dtype must be float32 or float16")
     scans = _dev(scans, torch.float32, "scans")
     if scans.dim() != 3:
         raise ValueError("scans must be [B,T,N]")
@@ -299,18 +302,19 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
     Ns = (N + stride - 1) // stride
     P = int(num_cutout_pts)
     if out is None:
-        out = torch.empty((B, Ns, T, P), dtype=torch.float32, device=scans.device)
+        out = torch.empty((B, Ns, T, P), dtype=out_dtype, device=scans.device)
     else:
-        _dev(out, torch.float32, "out")
+        _dev(out, out_dtype, "out")
         if tuple(out.shape) != (B, Ns, T, P):
             raise ValueError("out has the wrong shape")
+    entry = "pof_cutout_ex" if out_dtype == torch.float32 else "pof_cutout_f16"
     dbg = torch.empty((B, P, T, Ns), dtype=torch.int32, device=scans.device) if return_debug else None
     with torch.cuda.device(scans.device):
         step = 65535
         for s in range(0, B, step):
             n = min(step, B - s)
             ws = torch.empty(max(n, 1), dtype=torch.int32, device=scans.device)
-            _lib.call("pof_cutout_ex", _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
+            _lib.call(entry, _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
                       int(bool(fixed)), float(window_width), float(window_depth), P, float(padding_val),
                       int(bool(area_mode)), 0 if exact_values else 1, _ptr(out[s:s + n]), _ptr(ws),
                       _ptr(dbg[s:s + n]) if dbg is not None else None, _stream())

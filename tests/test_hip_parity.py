@@ -601,6 +601,22 @@ def test_cutout_float32_value_path(ops, golden, name):
         assert torch.equal(fast[sat], exact[sat])          # saturated samples are exactly +-1
 
 
+@pytest.mark.parametrize("name", sorted(CUTOUT_CASES))
+def test_cutout_float16_storage(ops, golden, name):
+    """BASELINE config 5 storage: the float16 output is the float32 result rounded once (bit-exact
+    against the exact path cast to half), for every geometry incl. the dense 3600-point one."""
+    g = golden("cutout")
+    inc, n, kw = CUTOUT_CASES[name]
+    tab = ops.phi_table(np.radians(inc), n)
+    scans = T(g[name + "_scans"])
+    exact = ops.cutout(scans, tab, **kw)
+    half = ops.cutout(scans, tab, out_dtype=torch.float16, **kw)
+    assert half.dtype == torch.float16 and half.shape == exact.shape
+    assert torch.equal(half, exact.to(torch.float16))
+    want = R.cutout(g[name + "_scans"][0], R.laser_phi(np.radians(inc), n), atan_mode="cr", **kw)
+    assert np.array_equal(half[0].cpu().numpy(), want.astype(np.float16))
+
+
 def test_cutout_float32_value_path_large(ops):
     """Same contract on 1.3e8 samples (2048 x 450 x 5 x 56, near-field legs included): the
     verify step must catch every index within rounding distance of an integer."""
