@@ -364,8 +364,8 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         const int area_sh = (N <= 4000) ? 19 : ((N <= 64000) ? 15 : 0);
         const int area_mask = (1 << area_sh) - 1;
         const double area_scale = (double)(1 << area_sh);
-        const double area_c1 = (AREA && VMODE == 2) ? step_a * rdphi * area_scale : 0.0;
-        const double area_c0 = (AREA && VMODE == 2) ? ((a0 - phi0) * rdphi + 0.5) * area_scale : 0.0;
+        const double area_c1 = AREA ? step_a * rdphi * area_scale : 0.0;
+        const double area_c0 = AREA ? ((a0 - phi0) * rdphi + 0.5) * area_scale : 0.0;
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
@@ -375,10 +375,11 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 if (AREA) {
                     // mean of s_area nearest-neighbour samples: float32 sum in order, float32 divide
                     float acc = 0.0f;
-                    if (VMODE == 2) {
+                    {
                         // rint(clip(ia)) as a fixed-point floor of ia + 0.5: one FMA and one
                         // saturating conversion per area sample; lanes within 2^-(sh-1) of a tie
-                        // (or out of fixed-point range) take the exact sequence
+                        // (or out of fixed-point range) take the exact sequence, so the index is
+                        // the reference's in every value mode
                         const double ub = fma((double)((k0 + u) * s_area), area_c1, area_c0);
                         for (int s = 0; s < s_area; ++s) {
                             const int q = (int)fma((double)s, area_c1, ub);
@@ -391,14 +392,6 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                                 ri = (int)rint(ia);
                             }
                             const float v = fetch(roff + min(max(ri, 0), N - 1));
-                            acc = (s == 0) ? v : acc + v;
-                        }
-                    } else {
-                        for (int s = 0; s < s_area; ++s) {
-                            double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
-                            ia = ia < 0.0 ? 0.0 : ia;
-                            ia = ia > nm1 ? nm1 : ia;
-                            const float v = fetch(roff + (int)rint(ia));
                             acc = (s == 0) ? v : acc + v;
                         }
                     }
