@@ -311,6 +311,17 @@ int pof_associate_odometry(const float *scans_t, const float *odoms_t, const flo
                            int32_t *idx0, int32_t *idx1, pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N4 scans_to_polar_grid                        src/utils/utils.py:492-531
+ * scans [B][T][N] float32 -> out [B][T][R][N] float32, R = int((max-min)/bin) + 1:
+ * the truncated-signed-distance column of every beam (the "fc2d" network input,
+ * src/utils/dataset_dr_spaam.py:455-458).  float32 arithmetic as NumPy >= 2 evaluates
+ * the reference (bit-exact against it); tsdf_clip <= 0 disables the distance ramp.
+ * ---------------------------------------------------------------------- */
+int pof_polar_grid(const float *scans, int B, int T, int N, double min_range, double max_range,
+                   double range_bin_size, double tsdf_clip, int normalize, float *out,
+                   pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N1, host side: numeric CSV -> float64 matrix (no device work, no stream).
  * Replaces np.genfromtxt(path, delimiter=",") for the DROW sequence files
  * (src/utils/dataset_dr_spaam.py:473-478 `.csv`, :504-509 `.odom2`, :497-502

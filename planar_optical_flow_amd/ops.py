@@ -325,6 +325,25 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
     return out
 
 
+def polar_grid(scans, min_range=0.0, max_range=30.0, range_bin_size=1.0, tsdf_clip=1.0, normalize=True, out=None):
+    """N4 for a batch: scans [B,T,N] float32 -> [B, T, R, N] float32, R = int((max-min)/bin) + 1."""
+    scans = _dev(scans, torch.float32, "scans")
+    if scans.dim() != 3:
+        raise ValueError("scans must be [B,T,N]")
+    B, T, N = scans.shape
+    R = int((max_range - min_range) / range_bin_size) + 1
+    if out is None:
+        out = torch.empty((B, T, R, N), dtype=torch.float32, device=scans.device)
+    else:
+        _dev(out, torch.float32, "out")
+        if tuple(out.shape) != (B, T, R, N):
+            raise ValueError("out has the wrong shape")
+    with torch.cuda.device(scans.device):
+        _lib.call("pof_polar_grid", _ptr(scans), B, T, N, float(min_range), float(max_range), float(range_bin_size),
+                  float(tsdf_clip), int(bool(normalize)), _ptr(out), _stream())
+    return out
+
+
 def nms_predicted_center(ranges, tab, pred_cls, pred_reg, min_dist=0.5):
     """A11 batched: ranges [B,N] f32, pred_cls [B,N] f64, pred_reg [B,N,2] f64 ->
     (det_xy [B,N,2], det_cls [B,N], num_det [B] int32, instance_mask [B,N] int32)."""

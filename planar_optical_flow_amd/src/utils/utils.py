@@ -253,6 +253,17 @@ def scans_to_cutout(scans, scan_phi, stride=1, centered=True, fixed=False, windo
     return out if tensor_in else out.cpu().numpy()
 
 
+def scans_to_polar_grid(scans, min_range=0.0, max_range=30.0, range_bin_size=1.0, tsdf_clip=1.0,
+                        normalize=True):
+    """:492-531.  scans (T,N) -> (T, R, N) float32 TSDF columns; a leading batch axis is accepted."""
+    tensor_in = _is_t(scans)
+    s = _to_dev(scans, torch.float32)
+    batched = s.dim() == 3
+    out = ops.polar_grid(s if batched else s[None], min_range, max_range, range_bin_size, tsdf_clip, normalize)
+    out = out if batched else out[0]
+    return out if tensor_in else out.cpu().numpy()
+
+
 def scans_to_cutout_torch(scans, scan_phi, stride=1, centered=True, fixed=False, window_width=1.66,
                           window_depth=1.0, num_cutout_pts=48, padding_val=29.99, area_mode=False):
     """:337-420.  The reference's torch twin does its index math in float32 and

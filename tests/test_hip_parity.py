@@ -380,6 +380,26 @@ def test_spatial_attention_band_shapes(ops, N, E, w):
     np.testing.assert_allclose(prob.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
 
 
+# ---------------------------------------------------------------- N4
+def test_polar_grid_bit_exact(ops, golden):
+    """scans_to_polar_grid against the reference's own outputs (golden) and the oracle: bit-exact,
+    incl. odd N (scalar path), out-of-range / infinite ranges and a batch axis."""
+    from test_oracle_golden import POLAR_CASES
+    g = golden("polar_grid")
+    for tag, kw in POLAR_CASES:
+        both = np.stack([g["scans0"], g["scans1"]])
+        got = ops.polar_grid(T(both), **kw).cpu().numpy()
+        for b in range(2):
+            assert np.array_equal(got[b], g["out%d_%s" % (b, tag)]), (b, tag)
+    rng = np.random.default_rng(3)
+    odd = rng.uniform(-2, 40, (3, 2, 451)).astype(np.float32)
+    odd[1, 1, 7] = np.inf
+    got = ops.polar_grid(T(odd), max_range=29.5, range_bin_size=0.5).cpu().numpy()
+    for b in range(3):
+        want = R.polar_grid(odd[b], max_range=29.5, range_bin_size=0.5)
+        assert np.array_equal(got[b], want, equal_nan=True)
+
+
 # ---------------------------------------------------------------- A13
 def test_segment_features_vs_oracle(ops):
     sb = synth.make_batch(seed=13, B=4, T=1, dropout=0.0)

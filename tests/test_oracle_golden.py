@@ -204,6 +204,18 @@ def test_n1_dataset_getitem(golden):
     assert R.window_indices(3) == [0, 0, 0, 0, 0] and R.window_indices(12) == [3, 4, 5, 6, 7]
 
 
+# ---- N4: polar TSDF grid ---------------------------------------------------------------------
+POLAR_CASES = [("default", {}), ("raw", dict(normalize=False)), ("noclip", dict(tsdf_clip=0.0)),
+               ("fine", dict(min_range=0.5, max_range=25.0, range_bin_size=0.25, tsdf_clip=2.0))]
+
+
+def test_polar_grid_oracle_equals_reference(golden):
+    g = golden("polar_grid")
+    for b in range(2):
+        for tag, kw in POLAR_CASES:
+            assert np.array_equal(R.polar_grid(g["scans%d" % b], **kw), g["out%d_%s" % (b, tag)]), (b, tag)
+
+
 # ---- N1: DROW file formats (host side; needs the library's CSV reader, no GPU) -------------
 def _write_drow_files(g, root):
     import os

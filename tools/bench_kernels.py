@@ -75,3 +75,11 @@ if "bwd" in which:
         ms = timeit(lambda: ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, 11), iters=10)
         per = 4 * N * F * 4 + 4 * N * E * 4 + 3 * N * 11 * 4     # read g, tmpl; write dx, dtmpl; emb in/out
         print("attn backward B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
+if "polar" in which:
+    B, Tn, N = 2048, 5, 450
+    sb = synth.make_batch(seed=3, B=B, T=Tn)
+    scans = torch.from_numpy(sb.scans).to(dev)
+    out = torch.empty((B, Tn, 31, N), dtype=torch.float32, device=dev)
+    ms = timeit(lambda: ops.polar_grid(scans, out=out))
+    byt = B * Tn * N * 4 * 32
+    print("polar grid B=%d T=%d: %.3f ms  %.0f GB/s" % (B, Tn, ms, byt / ms / 1e6))

@@ -368,6 +368,17 @@ def main():
     import shutil
     shutil.rmtree(tmp)
 
+    # ---------------- N4: scans_to_polar_grid -------------------------------------------------
+    gp = {}
+    sbp = synth.make_batch(seed=81, B=2, T=5)
+    cases = [("default", {}), ("raw", dict(normalize=False)), ("noclip", dict(tsdf_clip=0.0)),
+             ("fine", dict(min_range=0.5, max_range=25.0, range_bin_size=0.25, tsdf_clip=2.0))]
+    for b in range(2):
+        gp["scans%d" % b] = sbp.scans[b]
+        for tag, kwp in cases:
+            gp["out%d_%s" % (b, tag)] = u.scans_to_polar_grid(sbp.scans[b], **kwp)
+    np.savez_compressed(os.path.join(OUT, "polar_grid.npz"), **gp)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
