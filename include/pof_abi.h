@@ -311,6 +311,24 @@ int pof_associate_odometry(const float *scans_t, const float *odoms_t, const flo
                            int32_t *idx0, int32_t *idx1, pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105
+ *                                                src/data_handle/jrdb_handle.py:178-256
+ * points [Np][D] float64 (D = 2 or 3), centers [S][D], oris [S] -> per detection the
+ * radius query norm(points - centre) <= radius (float64), count[S] = segment size,
+ * and x [S][input_size][D+1] float32 = the reference's fixed-size resampling
+ * (random subset when larger, repeat + pad when smaller) of (point - centre, ori).
+ * Segments with fewer than min_segment_size points get zero rows (the caller skips
+ * them, as the reference returns None).  Randomness: a counter-based hash of
+ * (seed, detection index, point index); rows come out in hash order (the consumer is
+ * order invariant; the reference's order depends on the global NumPy RNG).
+ * mask (optional, [S][Np] uint8) receives the radius-query result itself
+ * (generate_segment / anns_to_segments return the variable-size segment).
+ * ---------------------------------------------------------------------- */
+int pof_segment_inputs(const double *points, int Np, int D, const double *centers, const double *oris,
+                       int S, double radius, int input_size, int min_segment_size, uint32_t seed,
+                       float *x, int32_t *count, uint8_t *mask, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N4 scans_to_polar_grid                        src/utils/utils.py:492-531
  * scans [B][T][N] float32 -> out [B][T][R][N] float32, R = int((max-min)/bin) + 1:
  * the truncated-signed-distance column of every beam (the "fc2d" network input,

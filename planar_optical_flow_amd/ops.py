@@ -325,6 +325,33 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
     return out
 
 
+def segment_inputs(points, centers, oris, radius=0.4, input_size=64, min_segment_size=5, seed=0,
+                   return_mask=False):
+    """N3: points [Np,D] f64, centers [S,D] f64, oris [S] f64 -> (x [S,input_size,D+1] f32, count [S] i32
+    [, mask [S,Np] bool]): radius query + fixed-size resampling of every detection's segment in one launch."""
+    points = _dev(points, torch.float64, "points")
+    centers = _dev(centers, torch.float64, "centers")
+    oris = _dev(oris, torch.float64, "oris")
+    if points.dim() != 2 or centers.dim() != 2 or points.shape[1] != centers.shape[1]:
+        raise ValueError("points [Np,D] and centers [S,D] must share D")
+    Np, D = points.shape
+    S = centers.shape[0]
+    if oris.numel() != S:
+        raise ValueError("one orientation per detection")
+    dev = points.device
+    x = torch.zeros((S, int(input_size), D + 1), dtype=torch.float32, device=dev)
+    count = torch.zeros((S,), dtype=torch.int32, device=dev)
+    mask = torch.zeros((S, Np), dtype=torch.uint8, device=dev) if return_mask else None
+    if S > 0 and Np > 0:
+        with torch.cuda.device(dev):
+            _lib.call("pof_segment_inputs", _ptr(points), Np, D, _ptr(centers), _ptr(oris), S, float(radius),
+                      int(input_size), int(min_segment_size), int(seed) & 0xFFFFFFFF, _ptr(x), _ptr(count),
+                      _ptr(mask) if mask is not None else None, _stream())
+    if return_mask:
+        return x, count, mask.bool()
+    return x, count
+
+
 def polar_grid(scans, min_range=0.0, max_range=30.0, range_bin_size=1.0, tsdf_clip=1.0, normalize=True, out=None):
     """N4 for a batch: scans [B,T,N] float32 -> [B, T, R, N] float32, R = int((max-min)/bin) + 1."""
     scans = _dev(scans, torch.float32, "scans")

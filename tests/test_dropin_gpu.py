@@ -290,3 +290,106 @@ def test_prepare_sequence_matches_data_prepare(golden, tmp_path):
     ref = np.stack([R.prepared_flow_target(scans[i], phi, t_r[i], d_r[i]) for i in range(len(scans))])
     np.testing.assert_allclose(flow, ref, atol=1e-12)
     np.testing.assert_allclose(drow_io.load_flow_file(base), ref, atol=6e-9)   # %10.8f text
+
+
+def test_segment_inputs_equal_reference_resampling():
+    """N3: one launch prepares every detection of a frame.  Against the oracle's radius query and
+    resampling rule (box_regressor.py:61-75): same segment size, every row is a segment point minus
+    the centre with the orientation appended, row multiplicities follow repeat + pad (small segments)
+    or form a subset without repetition (large segments); different seeds give different subsets."""
+    from planar_optical_flow_amd import ops
+    rng = np.random.default_rng(21)
+    for D in (2, 3):
+        pts = rng.uniform(-6, 6, (5000, D))
+        pts[:, 2:] *= 0.05
+        centers = np.array([pts[7], pts[100] + 0.05, np.full(D, 40.0), pts[5]])          # [3] is empty
+        dense = centers[0] + rng.normal(0, 0.1, (900, D))                                # > input_size points
+        pts = np.concatenate([pts, dense])
+        oris = np.array([0.3, -1.2, 0.0, 2.0])
+        x, count, mask = ops.segment_inputs(torch.from_numpy(pts).cuda(), torch.from_numpy(centers).cuda(),
+                                            torch.from_numpy(oris).cuda(), radius=0.4, input_size=64,
+                                            min_segment_size=5, seed=3, return_mask=True)
+        x, count, mask = x.cpu().numpy(), count.cpu().numpy(), mask.cpu().numpy()
+        for s in range(4):
+            seg = R.radius_query(pts, centers[s], 0.4)
+            assert count[s] == len(seg)
+            assert np.array_equal(pts[mask[s]], seg)
+            if len(seg) < 5:
+                assert not x[s].any()
+                continue
+            assert np.all(x[s][:, D] == np.float32(oris[s]))
+            want = (seg - centers[s]).astype(np.float32)
+            # every output row is one of the segment's rows; count how often each is used
+            used = np.zeros(len(want), dtype=int)
+            for row in x[s][:, :D]:
+                hit = np.where((want == row).all(axis=1))[0]
+                assert len(hit) >= 1
+                used[hit[0]] += 1
+            n = len(seg)
+            if n > 64:
+                assert used.max() == 1 and used.sum() == 64
+            else:
+                rep, pad = 64 // n, 64 % n
+                extra = -(-pad // rep) if pad else 0          # rows of the repeated array that are taken again
+                assert used.min() >= rep and used.sum() == 64
+                assert (used > rep).sum() == extra
+        x2, _ = ops.segment_inputs(torch.from_numpy(pts).cuda(), torch.from_numpy(centers).cuda(),
+                                   torch.from_numpy(oris).cuda(), seed=4)
+        assert not np.array_equal(x2[0].cpu().numpy(), x[0])          # another random subset of the dense segment
+        x3, _ = ops.segment_inputs(torch.from_numpy(pts).cuda(), torch.from_numpy(centers).cuda(),
+                                   torch.from_numpy(oris).cuda(), seed=3)
+        assert np.array_equal(x3.cpu().numpy(), x)                    # same seed: same rows, run to run
+
+
+def test_segment_inputs_huge_segment_is_uniform():
+    """More candidates than the LDS list holds: the hash pre-thinning still yields a subset without
+    repetition whose indices are spread over the whole segment."""
+    from planar_optical_flow_amd import ops
+    rng = np.random.default_rng(22)
+    pts = rng.normal(0, 0.1, (30000, 2))
+    x, count, mask = ops.segment_inputs(torch.from_numpy(pts).cuda(), torch.zeros(1, 2, dtype=torch.float64).cuda(),
+                                        torch.zeros(1, dtype=torch.float64).cuda(), radius=0.4, input_size=256,
+                                        seed=1, return_mask=True)
+    n = int(count[0])
+    assert n > 20000 and n == int(mask.sum())
+    rows = x[0].cpu().numpy()[:, :2]
+    assert len(np.unique(rows, axis=0)) == 256
+    src = pts[mask[0].cpu().numpy()].astype(np.float32)
+    order = {tuple(r): i for i, r in enumerate(src)}
+    idx = np.array([order[tuple(r)] for r in rows])
+    assert idx.min() < 0.1 * n and idx.max() > 0.9 * n            # not just the head of the segment
+
+
+def test_jrdb_anns_to_segments_and_transforms():
+    """N3 host mirror: anns_to_segments (all annotations of a frame in one launch) against the
+    reference's per-annotation formula with the same RNG stream; the six rigid transforms are
+    inverse pairs and match a float64 restatement."""
+    from planar_optical_flow_amd.src.data_handle.jrdb_handle import anns_to_segments, box_is_on_ground
+    from planar_optical_flow_amd.src.utils import jrdb_transforms as jt
+    rng = np.random.default_rng(31)
+    pts = rng.uniform(-5, 5, (4000, 3)).astype(np.float32)
+    anns = [{"box": {"cx": float(rng.uniform(-4, 4)), "cy": float(rng.uniform(-4, 4)), "cz": -0.2, "l": 0.8,
+                     "w": 0.6, "h": 1.7, "rot_z": 0.3}} for _ in range(9)]
+    for is_3d in (True, False):
+        segs, boxes, ctr = anns_to_segments(pts, anns, radius=0.7, perturb=0.1, is_3d=is_3d,
+                                            rng=np.random.default_rng(5))
+        ref_rng = np.random.default_rng(5)
+        assert boxes.shape == (9, 7 if is_3d else 5)
+        for s, ann in enumerate(anns):
+            alpha = ref_rng.uniform(0, 2 * np.pi)
+            r = ref_rng.uniform(-0.1, 0.1)
+            c = np.array([ann["box"]["cx"] + r * np.cos(alpha), ann["box"]["cy"] + r * np.sin(alpha)])
+            assert np.array_equal(ctr[s][:2], c)
+            keep = np.linalg.norm(pts[:, :2] - c, axis=1) <= 0.7
+            want = pts[keep] if is_3d else pts[:, :2][keep]
+            assert np.array_equal(segs[s], want)
+    assert box_is_on_ground({"box": {"cz": -0.2, "h": 1.7}}) and not box_is_on_ground({"box": {"cz": 0.5, "h": 1.0}})
+    p = rng.normal(0, 3, (3, 50)).astype(np.float32)
+    for fwd, inv, yaw, dz in ((jt.transform_pts_laser_to_base, jt.transform_pts_base_to_laser, np.pi / 120, 0.0),
+                              (jt.transform_pts_upper_velodyne_to_base, jt.transform_pts_base_to_upper_velodyne, 0.085, 0.33529),
+                              (jt.transform_pts_lower_velodyne_to_base, jt.transform_pts_base_to_lower_velodyne, 0.0, -0.13511)):
+        q = fwd(p)
+        c, s = np.cos(yaw), np.sin(yaw)
+        want = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]) @ p.astype(np.float64) + np.array([[0], [0], [dz]])
+        np.testing.assert_allclose(q, want, atol=2e-6)
+        np.testing.assert_allclose(inv(q), p, atol=2e-6)
