@@ -62,3 +62,147 @@ class _SpatialAttention(nn.Module):
         emb_t = self.conv(x_template.reshape(B * N, C, P)).view(B, N, 128)
         out, band = _WindowedAttention.apply(emb_x, emb_t, x, x_template, self._alpha, self._window_size)
         return out, band
+
+
+# ---------------------------------------------------------------------------------------
+# DROW / SpatialDROW / FlowDROW_pretrained (reference :8-19, :41-121, :220-322).
+# Same sub-module names, construction order and initialisation as the reference, so a
+# reference checkpoint loads with load_state_dict and a seeded construction reproduces the
+# reference's weights.  The conv trunks stay dense MIOpen work; the temporal gate is the
+# HIP attention above.
+# ---------------------------------------------------------------------------------------
+def _conv(in_channel, out_channel, kernel_size, padding):
+    return nn.Sequential(nn.Conv1d(in_channel, out_channel, kernel_size=kernel_size, padding=padding),
+                         nn.BatchNorm1d(out_channel), nn.LeakyReLU(negative_slope=0.1, inplace=True))
+
+
+def _conv3x3(in_channel, out_channel):
+    return _conv(in_channel, out_channel, kernel_size=3, padding=1)
+
+
+def _init_weights(module):
+    for m in module.modules():
+        if isinstance(m, (nn.Conv1d, nn.Conv2d)):
+            nn.init.kaiming_normal_(m.weight, a=0.1, nonlinearity="leaky_relu")
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            nn.init.constant_(m.weight, 1)
+            nn.init.constant_(m.bias, 0)
+
+
+class DROW(nn.Module):
+    """Per-point detector on cutouts [B, n_cutout, n_scan, n_pts] -> (pred_cls [B, n_cutout, 4|1],
+    pred_reg [B, n_cutout, 2]); the scans of a window are fused by summation (:41-121)."""
+
+    _TRUNK = ((1, 64, 64, 128), (128, 128, 128, 256), (256, 256, 256, 512))
+
+    def __init__(self, dropout=0.5, num_scans=5, num_pts=48, focal_loss_gamma=0.0, pedestrian_only=False):
+        super().__init__()
+        import torch.nn.functional as F
+        from .loss_utils import BinaryFocalLoss, FocalLoss
+        self.dropout = 0.0   # the reference ignores its `dropout` argument (:47-48)
+        for b, ch in enumerate(self._TRUNK, start=1):
+            setattr(self, "conv_block_%d" % b, nn.Sequential(*[_conv3x3(ch[i], ch[i + 1]) for i in range(3)]))
+        self.conv_block_4 = nn.Sequential(_conv3x3(512, 256), _conv3x3(256, 128))
+        if pedestrian_only:
+            self.conv_cls = nn.Conv1d(128, 1, kernel_size=1)
+            self.cls_loss = BinaryFocalLoss(gamma=focal_loss_gamma) if focal_loss_gamma > 0.0 \
+                else F.binary_cross_entropy
+        else:
+            self.conv_cls = nn.Conv1d(128, 4, kernel_size=1)
+            self.cls_loss = FocalLoss(gamma=focal_loss_gamma) if focal_loss_gamma > 0.0 else F.cross_entropy
+        self.conv_reg = nn.Conv1d(128, 2, kernel_size=1)
+        _init_weights(self)
+
+    def _forward_conv(self, x, conv_block):
+        out = torch.max_pool1d(conv_block(x), kernel_size=2)
+        if self.dropout > 0:
+            out = torch.dropout(out, self.dropout, self.training)
+        return out
+
+    def _forward_cutout(self, x):
+        B, N, T, P = x.shape
+        out = self._forward_conv(x.reshape(B * N * T, 1, P), self.conv_block_1)
+        out = self._forward_conv(out, self.conv_block_2)
+        return out.view(B, N, T, out.shape[-2], out.shape[-1])
+
+    def _fuse_cutout(self, x):
+        return torch.sum(x, dim=2)
+
+    def _forward_fused_cutout(self, x):
+        B, N, C, P = x.shape
+        out = self._forward_conv(x.reshape(B * N, C, P), self.conv_block_3)
+        out = self.conv_block_4(out)
+        out = torch.nn.functional.avg_pool1d(out, kernel_size=out.shape[-1])
+        return self.conv_cls(out).view(B, N, -1), self.conv_reg(out).view(B, N, 2)
+
+    def forward(self, x):
+        return self._forward_fused_cutout(self._fuse_cutout(self._forward_cutout(x)))
+
+
+class SpatialDROW(DROW):
+    """DR-SPAAM: the per-scan features are fused auto-regressively through the windowed spatial
+    attention gate instead of being summed (:220-277)."""
+
+    def __init__(self, dropout=0.5, num_scans=5, num_pts=48, focal_loss_gamma=0.0, alpha=0.5, window_size=7,
+                 pedestrian_only=False):
+        super().__init__(dropout=dropout, num_scans=num_scans, num_pts=num_pts,
+                         focal_loss_gamma=focal_loss_gamma, pedestrian_only=pedestrian_only)
+        from math import ceil
+        self.gate = _SpatialAttention(n_pts=int(ceil(num_pts / 4)), n_channel=256, alpha=alpha,
+                                      window_size=window_size)
+        self.loss_fn = flow_loss
+
+    def _scan_features(self, x, t):
+        return self._forward_cutout(x[:, :, t, :].unsqueeze(dim=2)).squeeze(dim=2)
+
+    def forward(self, x, testing=False, fea_template=None):
+        if testing:   # streaming inference: one new scan against the running template
+            out = self._scan_features(x, 0)
+            if fea_template is None:
+                out_template = out.clone()
+                _, feat_fused = self.gate(out, out_template)
+            else:
+                out_template, feat_fused = self.gate(out, fea_template)
+            pred_cls, pred_reg = self._forward_fused_cutout(out_template)
+            return pred_cls, pred_reg, out_template, feat_fused
+        n_scan = x.shape[2]
+        out_template = self._scan_features(x, 0)
+        for i in range(1, n_scan - 1):
+            out_template, _ = self.gate(self._scan_features(x, i), out_template)
+        out_template, feat_fused = self.gate(self._scan_features(x, n_scan - 1), out_template)
+        pred_cls, pred_reg = self._forward_fused_cutout(out_template)
+        return pred_cls, pred_reg, feat_fused
+
+
+class FlowDROW_pretrained(nn.Module):
+    """Frozen DR-SPAAM + a small conv head on the window similarities (plus the current range) that
+    regresses the per-point flow (:279-322).  ``pre_trained_ckpt=None`` skips the checkpoint load
+    (the reference always loads ./pre_trained_ckpts/dr_spaam_e40.pth)."""
+
+    def __init__(self, dropout=0.5, num_scans=5, num_pts=48, focal_loss_gamma=0.0, alpha=0.5, window_size=7,
+                 pedestrian_only=False, pre_trained_ckpt="./pre_trained_ckpts/dr_spaam_e40.pth"):
+        super().__init__()
+        self.dr_spaam = SpatialDROW(num_scans=num_scans, num_pts=num_pts, focal_loss_gamma=focal_loss_gamma,
+                                    alpha=alpha, window_size=window_size, pedestrian_only=pedestrian_only)
+        if pre_trained_ckpt is not None:
+            ckpt = torch.load(pre_trained_ckpt, map_location="cpu", weights_only=False)
+            self.dr_spaam.load_state_dict(ckpt["model_state"] if "model_state" in ckpt else ckpt)
+        for param in self.dr_spaam.parameters():
+            param.requires_grad = False
+        self.conv1 = _conv(window_size, 128, kernel_size=3, padding=1)
+        self.conv2 = _conv(128, 64, kernel_size=3, padding=1)
+        self.conv3 = _conv(64, 32, kernel_size=3, padding=1)
+        self.pw = _conv(32, 2, kernel_size=1, padding=0)
+        self.loss_fn = flow_loss
+        self._feat = None
+
+    def forward(self, x, cur_scan, testing=False, fea_template=None):
+        if testing:
+            pred_cls, pred_reg, self._feat, feat_fused = self.dr_spaam(x, testing=testing, fea_template=self._feat)
+        else:
+            pred_cls, pred_reg, feat_fused = self.dr_spaam(x)
+        # the reference's two permutes cancel: conv1 sees [B, n_cutout, window + 1], i.e. it treats the
+        # cutouts as channels -- which only has the right shape when n_cutout == window_size (:311-314)
+        feat = torch.cat((feat_fused, cur_scan.unsqueeze(dim=-1)), dim=-1)
+        out = self.conv3(self.conv2(self.conv1(feat)))
+        return pred_cls, pred_reg, self.pw(out).permute(0, 2, 1)

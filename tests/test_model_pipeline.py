@@ -110,3 +110,17 @@ def test_collate_batch_stacks_like_reference():
     out = collate_batch(samples)
     assert out["scans"].shape == (5, 3, 4) and out["target_cls"].shape == (5, 4)
     assert out["seq_name"] == ["s0", "s1", "s2", "s3", "s4"]
+
+
+def test_spatial_drow_state_dict_equals_reference(golden):
+    """N2: same sub-module names, construction order and initialisation as the reference: a seeded
+    construction reproduces every tensor of the reference's state dict (88 entries, 1 977 667 params)."""
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    g = golden("dr_spaam_model")
+    torch.manual_seed(3)
+    m = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g["keys"]]
+    assert sum(p.numel() for p in m.parameters()) == 1977667
+    got = np.array([float(v.double().abs().sum()) for v in sd.values()])
+    np.testing.assert_allclose(got, g["abs_sum"], rtol=1e-12)

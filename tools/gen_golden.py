@@ -379,6 +379,34 @@ def main():
             gp["out%d_%s" % (b, tag)] = u.scans_to_polar_grid(sbp.scans[b], **kwp)
     np.savez_compressed(os.path.join(OUT, "polar_grid.npz"), **gp)
 
+    # ---------------- N2: DROW / SpatialDROW forward (weights rebuilt from the seed) ------------
+    gm = {}
+    torch.manual_seed(3)
+    mref = spaam.SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+    gm["keys"] = np.array(list(mref.state_dict().keys()))
+    gm["abs_sum"] = np.array([float(v.double().abs().sum()) for v in mref.state_dict().values()])
+    xin = torch.randn(2, 30, 5, 56) * 0.5
+    gm["x"] = xin.numpy()
+    mref.eval()
+    with torch.no_grad():
+        pc, pr, ff = mref(xin)
+        gm["eval_cls"], gm["eval_reg"], gm["eval_feat"] = pc.numpy(), pr.numpy(), ff.numpy()
+        # streaming inference: two consecutive scans through the running template
+        c0, r0, tmpl0, f0 = mref(xin[:, :, 3:4], testing=True)
+        c1, r1, tmpl1, f1 = mref(xin[:, :, 4:5], testing=True, fea_template=tmpl0)
+        gm["stream_cls"], gm["stream_reg"], gm["stream_feat"] = c1.numpy(), r1.numpy(), f1.numpy()
+    mref.train()
+    pc, pr, ff = mref(xin)                       # BatchNorm with batch statistics
+    gm["train_cls"], gm["train_reg"], gm["train_feat"] = pc.detach().numpy(), pr.detach().numpy(), ff.detach().numpy()
+    torch.manual_seed(4)
+    dref = spaam.DROW(num_scans=5, num_pts=48)
+    dref.eval()
+    xd = torch.randn(2, 25, 5, 48) * 0.5
+    with torch.no_grad():
+        dc, dr_ = dref(xd)
+    gm["drow_x"], gm["drow_cls"], gm["drow_reg"] = xd.numpy(), dc.numpy(), dr_.numpy()
+    np.savez_compressed(os.path.join(OUT, "dr_spaam_model.npz"), **gm)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
