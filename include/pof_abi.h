@@ -311,6 +311,18 @@ int pof_associate_odometry(const float *scans_t, const float *odoms_t, const flo
                            int32_t *idx0, int32_t *idx1, pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N2 DROW / DR-SPAAM trunk layer, inference     src/depracted/model/dr_spaam.py:8-19, :86-92
+ * y = max_pool1d?(LeakyReLU(BatchNorm_eval(Conv1d(k=3, pad=1)(x))), 2) on S sequences:
+ * x [S][Ci][L] float32 -> out [S][Co][pool ? L/2 : L].  wt = conv weight transposed to
+ * [3][Ci][Co]; scale[Co] = gamma / sqrt(running_var + eps), shift[Co] = beta +
+ * (conv_bias - running_mean) * scale (the caller folds them once per checkpoint).
+ * Implicit GEMM on the float32 MFMA (exact float32 products, k-ordered accumulation).
+ * ---------------------------------------------------------------------- */
+int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
+                       int S, int Ci, int Co, int L, int pool, double negative_slope, float *out,
+                       pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105
  *                                                src/data_handle/jrdb_handle.py:178-256
  * points [Np][D] float64 (D = 2 or 3), centers [S][D], oris [S] -> per detection the

@@ -325,6 +325,31 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
     return out
 
 
+def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None):
+    """N2 trunk layer (inference): x [S,Ci,L] f32, wt [3,Ci,Co] f32 (conv weight transposed), scale/shift [Co]
+    (folded BatchNorm + bias) -> [S, Co, L//2 if pool else L]."""
+    x = _dev(x, torch.float32, "x")
+    wt = _dev(wt, torch.float32, "wt")
+    scale = _dev(scale, torch.float32, "scale")
+    shift = _dev(shift, torch.float32, "shift")
+    S, Ci, L = x.shape
+    if wt.dim() != 3 or wt.shape[0] != 3 or wt.shape[1] != Ci:
+        raise ValueError("wt must be [3, Ci, Co]")
+    Co = wt.shape[2]
+    if scale.numel() != Co or shift.numel() != Co:
+        raise ValueError("scale / shift must have Co entries")
+    Lout = L // 2 if pool else L
+    if out is None:
+        out = torch.empty((S, Co, Lout), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, torch.float32, "out")
+    if S > 0:
+        with torch.cuda.device(x.device):
+            _lib.call("pof_conv3_bn_lrelu", _ptr(x), _ptr(wt), _ptr(scale), _ptr(shift), S, Ci, Co, L,
+                      int(bool(pool)), float(negative_slope), _ptr(out), _stream())
+    return out
+
+
 def segment_inputs(points, centers, oris, radius=0.4, input_size=64, min_segment_size=5, seed=0,
                    return_mask=False):
     """N3: points [Np,D] f64, centers [S,D] f64, oris [S] f64 -> (x [S,input_size,D+1] f32, count [S] i32

@@ -54,12 +54,19 @@ class _SpatialAttention(nn.Module):
                 nn.init.constant_(m.weight, 1)
                 nn.init.constant_(m.bias, 0)
 
+    def _embed(self, flat):
+        """The embedding conv spans the whole cutout (kernel_size = n_pts), i.e. it is the dense product
+        [B*N, C*P] x [C*P, 128]: run it as one library GEMM (same parameters, same gradients) instead of
+        a convolution, then the module's own BatchNorm and LeakyReLU."""
+        conv, bn, act = self.conv[0], self.conv[1], self.conv[2]
+        return act(bn(torch.nn.functional.linear(flat, conv.weight.reshape(conv.out_channels, -1), conv.bias)))
+
     def forward(self, x, x_template):
         """x, x_template [B, n_cutout, n_channel, n_pts] -> (fused template of the
         same shape, pre-softmax window similarities [B, n_cutout, window])."""
         B, N, C, P = x.shape
-        emb_x = self.conv(x.reshape(B * N, C, P)).view(B, N, 128)
-        emb_t = self.conv(x_template.reshape(B * N, C, P)).view(B, N, 128)
+        emb_x, emb_t = self._embed(x.reshape(B * N, C * P)).view(B, N, 128), \
+            self._embed(x_template.reshape(B * N, C * P)).view(B, N, 128)
         out, band = _WindowedAttention.apply(emb_x, emb_t, x, x_template, self._alpha, self._window_size)
         return out, band
 
@@ -113,8 +120,44 @@ class DROW(nn.Module):
         self.conv_reg = nn.Conv1d(128, 2, kernel_size=1)
         _init_weights(self)
 
+    # ---- inference on the HIP trunk kernels ------------------------------------------------
+    def fuse_for_inference(self, enable=True):
+        """Fold every conv3 + BatchNorm (running statistics) + bias of the four trunk blocks into
+        (transposed weight, scale, shift) triples for ``pof_conv3_bn_lrelu``.  Call after loading a
+        checkpoint and after ``.cuda()``; eval-mode forwards then run the trunk as float32-MFMA
+        implicit GEMMs instead of MIOpen convolutions.  Training mode always uses the torch modules."""
+        self._fused = None
+        if not enable:
+            return self
+        fused = {}
+        with torch.no_grad():
+            for name in ("conv_block_1", "conv_block_2", "conv_block_3", "conv_block_4"):
+                layers = []
+                for unit in getattr(self, name):
+                    conv, bn = unit[0], unit[1]
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    shift = bn.bias + (conv.bias - bn.running_mean) * scale
+                    layers.append((conv.weight.permute(2, 1, 0).contiguous().float(), scale.float().contiguous(),
+                                   shift.float().contiguous()))
+                fused[name] = layers
+        self._fused = fused
+        return self
+
+    def _run_block(self, x, name, pool):
+        """One trunk block; pooled blocks pool after their last layer."""
+        fused = getattr(self, "_fused", None)
+        if fused is not None and not self.training and x.is_cuda and not torch.is_grad_enabled():
+            out = x.contiguous().float()
+            layers = fused[name]
+            for i, (wt, scale, shift) in enumerate(layers):
+                out = ops.conv3_bn_lrelu(out, wt, scale, shift, pool=pool and i == len(layers) - 1)
+            return out
+        out = getattr(self, name)(x)
+        return torch.max_pool1d(out, kernel_size=2) if pool else out
+
     def _forward_conv(self, x, conv_block):
-        out = torch.max_pool1d(conv_block(x), kernel_size=2)
+        name = next(n for n in ("conv_block_1", "conv_block_2", "conv_block_3") if getattr(self, n) is conv_block)
+        out = self._run_block(x, name, pool=True)
         if self.dropout > 0:
             out = torch.dropout(out, self.dropout, self.training)
         return out
@@ -131,7 +174,7 @@ class DROW(nn.Module):
     def _forward_fused_cutout(self, x):
         B, N, C, P = x.shape
         out = self._forward_conv(x.reshape(B * N, C, P), self.conv_block_3)
-        out = self.conv_block_4(out)
+        out = self._run_block(out, "conv_block_4", pool=False)
         out = torch.nn.functional.avg_pool1d(out, kernel_size=out.shape[-1])
         return self.conv_cls(out).view(B, N, -1), self.conv_reg(out).view(B, N, 2)
 

@@ -415,6 +415,13 @@ def test_spatial_drow_forward_equals_reference(golden):
         np.testing.assert_allclose(c1.cpu().numpy(), g["stream_cls"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(r1.cpu().numpy(), g["stream_reg"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(f1.cpu().numpy(), g["stream_feat"], rtol=1e-3, atol=2e-3)
+        # the same forwards with the trunk on the HIP conv kernels (BatchNorm folded)
+        m.fuse_for_inference()
+        pc2, pr2, ff2 = m(x)
+        np.testing.assert_allclose(pc2.cpu().numpy(), g["eval_cls"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(pr2.cpu().numpy(), g["eval_reg"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(ff2.cpu().numpy(), g["eval_feat"], rtol=1e-3, atol=2e-3)
+        np.testing.assert_allclose(pc2.cpu().numpy(), pc.cpu().numpy(), rtol=1e-4, atol=1e-5)
     m.train()
     pc, pr, ff = m(x)
     np.testing.assert_allclose(pc.detach().cpu().numpy(), g["train_cls"], rtol=2e-3, atol=1e-3)

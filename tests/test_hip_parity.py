@@ -652,3 +652,33 @@ def test_cutout_float32_value_path_large(ops):
     assert diff.max().item() <= 1e-5, diff.max().item()
     # an index off by one would move a sample by a whole range step: count anything above 1e-5
     assert int((diff > 1e-5).sum()) == 0
+
+
+# ---------------------------------------------------------------- N2 trunk layer
+@pytest.mark.parametrize("S,Ci,Co,L,pool", [(5, 1, 64, 56, False), (3, 64, 64, 56, False), (7, 64, 128, 56, True),
+                                            (9, 128, 256, 28, True), (4, 512, 256, 7, False), (11, 5, 70, 10, True),
+                                            (1, 3, 1, 1, False), (2, 33, 130, 9, False)])
+def test_conv3_bn_lrelu_layer(ops, S, Ci, Co, L, pool):
+    """pof_conv3_bn_lrelu against torch (Conv1d k=3 pad=1 -> BatchNorm eval -> LeakyReLU 0.1 -> max_pool1d 2):
+    exact on integer data (indexing, borders, channel / column tails), 1e-4 on random float data."""
+    gen = torch.Generator(device="cpu").manual_seed(S * 1000 + Ci)
+    def reference(x, w, scale, shift, slope=0.1):
+        y = torch.nn.functional.conv1d(x, w, None, padding=1) * scale[None, :, None] + shift[None, :, None]
+        y = torch.nn.functional.leaky_relu(y, slope)
+        return torch.max_pool1d(y, 2) if pool else y
+    # integer data, power-of-two scale and slope: every float32 operation is exact
+    x = torch.randint(-3, 4, (S, Ci, L), generator=gen).float().to(DEV)
+    w = torch.randint(-2, 3, (Co, Ci, 3), generator=gen).float().to(DEV)
+    scale = torch.full((Co,), 0.5, device=DEV)
+    shift = torch.randint(-4, 5, (Co,), generator=gen).float().to(DEV)
+    got = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, pool=pool, negative_slope=0.125)
+    want = reference(x.double(), w.double(), scale.double(), shift.double(), 0.125).float()
+    assert got.shape == want.shape
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    x = torch.randn((S, Ci, L), generator=gen).to(DEV)
+    w = (torch.randn((Co, Ci, 3), generator=gen) / (3 * Ci) ** 0.5).to(DEV)
+    scale = (torch.rand((Co,), generator=gen) + 0.5).to(DEV)
+    shift = torch.randn((Co,), generator=gen).to(DEV)
+    got = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, pool=pool)
+    want = reference(x.double(), w.double(), scale.double(), shift.double()).float()
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
