@@ -17,6 +17,8 @@
 //     load feeds 4 MFMAs; loads are issued a block of 8 k-steps ahead.
 //   * epilogue: y = acc * scale[co] + shift[co] (BatchNorm folded with the conv bias), LeakyReLU,
 //     optional max over position pairs (adjacent lanes), store.
+#include <type_traits>
+
 #include "pof_common.h"
 
 namespace {
@@ -37,10 +39,12 @@ struct ConvArgs {
 };
 
 template <int CT>
-__global__ __launch_bounds__(64 * kCvWaves) void conv3_kernel(ConvArgs a)
+__global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_kernel(ConvArgs a)
 {
     constexpr int COG = 32 * CT;                       // output channels per workgroup
-    __shared__ float s_w[kCvRows][COG];
+    constexpr int NT = 64 * kCvWaves;
+    constexpr int NP = kCvCC / 2;                      // channel pairs (k-steps) per tap and chunk
+    __shared__ __attribute__((aligned(16))) float s_w[2][kCvRows][COG];   // double-buffered weight chunk
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const int co0 = blockIdx.y * COG;
@@ -49,46 +53,122 @@ __global__ __launch_bounds__(64 * kCvWaves) void conv3_kernel(ConvArgs a)
     const bool col_ok = n_g < ncol;
     const long long nc = col_ok ? n_g : ncol - 1;
     const int seq = (int)(nc / a.L), l = (int)(nc - (long long)seq * a.L);
-    const float *xs = a.x + (long long)seq * a.Ci * a.L + l;                    // x[seq][0][l]
     const bool tap_ok[3] = {col_ok && l > 0, col_ok, col_ok && l < a.L - 1};
+    // 32-bit element offsets of x[seq][h][l + tap - 1] relative to the (uniform) channel row base:
+    // border / tail lanes point at a valid neighbour and are zeroed after the load
+    // (BYTE offsets: SGPR base + zero-extended 32-bit VGPR offset is the global_load saddr form,
+    // which needs no 64-bit address registers per load)
+    const unsigned base_off = (unsigned)((long long)seq * a.Ci * a.L + l);
+    unsigned off_h[3], off_0[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        off_0[tap] = (base_off + (tap_ok[tap] ? tap - 1 : 0)) * 4u;
+        off_h[tap] = off_0[tap] + (unsigned)(h * a.L) * 4u;
+    }
+    const int nchunk = (a.Ci + kCvCC - 1) / kCvCC;
+
+    // weight chunk -> registers (16-byte loads along co; uniform chunk base + per-thread byte offsets
+    // that do not change from chunk to chunk), registers -> LDS
+    constexpr int WV = (kCvRows * COG / 4 + NT - 1) / NT;       // float4 groups per thread and chunk
+    using F4V = float __attribute__((ext_vector_type(4)));
+    F4V wreg[WV];
+    unsigned woff[WV];      // ((tap * Ci + cl) * Co + c) * 4 bytes
+    int wcl[WV];            // cl, or kCvCC when the group is outside the tile / the tensor
+    const bool wvec = (a.Co & 3) == 0;
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+        const int e4 = threadIdx.x + q * NT;
+        const int row = e4 / (COG / 4), c = (e4 - row * (COG / 4)) * 4;
+        const int tap = row / kCvCC, cl = row - tap * kCvCC;
+        const bool in = e4 < kCvRows * COG / 4 && co0 + c < a.Co;
+        woff[q] = in ? (unsigned)(((long long)tap * a.Ci + cl) * a.Co + c) * 4u : 0u;
+        wcl[q] = in ? cl : kCvCC;
+    }
+    auto load_w = [&](int ci0) {
+        const int cc = min(kCvCC, a.Ci - ci0);
+        const char *wbase = reinterpret_cast<const char *>(a.wt + (long long)ci0 * a.Co + co0);   // uniform
+#pragma unroll
+        for (int q = 0; q < WV; ++q) {
+            F4V v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (wcl[q] < cc) {
+                if (wvec) {
+                    v = *reinterpret_cast<const F4V *>(wbase + woff[q]);
+                } else {   // Co not a multiple of 4: element-wise with a column guard
+                    const float *pw = reinterpret_cast<const float *>(wbase + woff[q]);
+                    const int e4 = threadIdx.x + q * NT;
+                    const int c = (e4 % (COG / 4)) * 4;
+                    for (int j = 0; j < 4; ++j) v[j] = (co0 + c + j < a.Co) ? pw[j] : 0.0f;
+                }
+            }
+            wreg[q] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WV; ++q) {
+            const int e4 = threadIdx.x + q * NT;
+            if (e4 < kCvRows * COG / 4) reinterpret_cast<F4V *>(&s_w[buf][0][0])[e4] = wreg[q];
+        }
+    };
+    // activation operands of one chunk: 3 taps x NP channel pairs, uniform row base + lane offset
+    float xb[2][3][NP];
+    auto load_x = [&](int set, int ci0) {
+        const int cc = min(kCvCC, a.Ci - ci0);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int c2 = min(2 * p, cc - 1);                               // uniform
+                const char *rowp = reinterpret_cast<const char *>(a.x + (long long)(ci0 + c2) * a.L);  // uniform base
+                const bool pair = 2 * p + 1 < cc;                                // uniform: the odd channel exists
+                xb[set][tap][p] = *reinterpret_cast<const float *>(rowp + (pair ? off_h[tap] : off_0[tap]));
+            }
+    };
 
     f32x16 acc[CT];
 #pragma unroll
     for (int t = 0; t < CT; ++t) acc[t] = f32x16{0};
 
-    for (int ci0 = 0; ci0 < a.Ci; ci0 += kCvCC) {
+    load_w(0);
+    load_x(0, 0);
+    store_w(0);
+    __syncthreads();
+    auto chunk = [&](auto set_tag, const int ch) {
+        constexpr int SET = decltype(set_tag)::value;          // activation set / LDS buffer of this chunk
+        const int ci0 = ch * kCvCC;
         const int cc = min(kCvCC, a.Ci - ci0);
-        __syncthreads();
-        // weight chunk: rows (tap, ci_local), columns co0 .. co0 + COG
-        for (int e = threadIdx.x; e < kCvRows * COG; e += 64 * kCvWaves) {
-            const int row = e / COG, c = e - row * COG;
-            const int tap = row / kCvCC, cl = row - tap * kCvCC;
-            const bool ok = cl < cc && co0 + c < a.Co;
-            s_w[row][c] = ok ? a.wt[((long long)tap * a.Ci + ci0 + cl) * a.Co + co0 + c] : 0.0f;
+        const bool more = ch + 1 < nchunk;
+        if (more) {                       // next chunk's weights and activations are in flight during the MFMAs
+            load_w(ci0 + kCvCC);
+            load_x(SET ^ 1, ci0 + kCvCC);
         }
+        // A operand one k-step ahead of its MFMAs
+        float a_cur[CT], a_nxt[CT];
+#pragma unroll
+        for (int t = 0; t < CT; ++t) a_cur[t] = s_w[SET][h][t * 32 + r];
+#pragma unroll
+        for (int ks = 0; ks < 3 * NP; ++ks) {
+            const int tap = ks / NP, p = ks - tap * NP;
+            if (ks + 1 < 3 * NP) {
+                const int tn = (ks + 1) / NP, pn = (ks + 1) - tn * NP;
+#pragma unroll
+                for (int t = 0; t < CT; ++t) a_nxt[t] = s_w[SET][tn * kCvCC + 2 * pn + h][t * 32 + r];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool ok = tap_ok[tap] && (2 * p + h < cc);
+            const float bv = ok ? xb[SET][tap][p] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bv, acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < CT; ++t) a_cur[t] = a_nxt[t];
+        }
+        if (more) store_w(SET ^ 1);
         __syncthreads();
-        // activations of the whole chunk first (3 taps x 8 channel pairs = 24 loads in flight)
-        float xb[3][kCvCC / 2];
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-            for (int p = 0; p < kCvCC / 2; ++p) {
-                const int cl = min(2 * p + h, cc - 1);                          // clamped: masked below
-                // border / tail lanes read a valid neighbour address (clamped tap offset), zeroed afterwards
-                const int off = tap_ok[tap] ? tap - 1 : 0;
-                xb[tap][p] = xs[(long long)(ci0 + cl) * a.L + off];
-            }
-#pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
-#pragma unroll
-            for (int p = 0; p < kCvCC / 2; ++p) {
-                const bool ok = tap_ok[tap] && (2 * p + h < cc);
-                const float bv = ok ? xb[tap][p] : 0.0f;
-                const int row = tap * kCvCC + 2 * p + h;
-#pragma unroll
-                for (int t = 0; t < CT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w[row][t * 32 + r], bv, acc[t], 0, 0, 0);
-            }
+    };
+    for (int ch = 0; ch < nchunk; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, ch + 1);
     }
     // epilogue.  C/D layout: col = lane & 31 (column n), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (co)
     const int Lout = a.pool ? a.L / 2 : a.L;
@@ -126,6 +206,7 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
     ConvArgs a;
     a.x = x; a.wt = wt; a.scale = scale; a.shift = shift; a.out = out;
     a.S = S; a.Ci = Ci; a.Co = Co; a.L = L; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
+    if ((long long)S * Ci * L >= (1LL << 30)) return POF_E_SHAPE;   // 32-bit byte offsets per lane; callers chunk S
     const long long ncol = (long long)S * L;
     const long long tiles = (ncol + 31) / 32;
     const long long gx = (tiles + kCvWaves - 1) / kCvWaves;

@@ -1,0 +1,28 @@
+"""Per-layer timing of pof_conv3_bn_lrelu at the DR-SPAAM shapes (B = 32 -> 72000 / 14400 sequences)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from planar_optical_flow_amd import ops
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+SA, SC = B * 450 * 5, B * 450
+layers = [(SA, 1, 64, 56, 0), (SA, 64, 64, 56, 0), (SA, 64, 128, 56, 1), (SA, 128, 128, 28, 0), (SA, 128, 128, 28, 0),
+          (SA, 128, 256, 28, 1), (SC, 256, 256, 14, 0), (SC, 256, 256, 14, 0), (SC, 256, 512, 14, 1),
+          (SC, 512, 256, 7, 0), (SC, 256, 128, 7, 0)]
+tot_ms = tot_fl = 0.0
+for (S, Ci, Co, L, pool) in layers:
+    x = torch.randn((S, Ci, L), device="cuda")
+    wt = torch.randn((3, Ci, Co), device="cuda") * 0.05
+    sc = torch.ones(Co, device="cuda"); sh = torch.zeros(Co, device="cuda")
+    out = torch.empty((S, Co, L // 2 if pool else L), device="cuda")
+    for _ in range(2): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 5
+    fl = 2.0 * S * L * Co * Ci * 3
+    byt = 4.0 * S * (Ci * L + Co * (L // 2 if pool else L))
+    tot_ms += ms; tot_fl += fl
+    print("S=%6d Ci=%3d Co=%3d L=%2d pool=%d: %7.3f ms  %6.1f TFLOP/s  %6.0f GB/s" % (S, Ci, Co, L, pool, ms, fl / ms / 1e9, byt / ms / 1e6), flush=True)
+print("trunk total %.2f ms  %.1f TFLOP/s" % (tot_ms, tot_fl / tot_ms / 1e9))
