@@ -307,6 +307,7 @@ def main():
             result["cutout"] = bench_cutout(ops, synth, tab, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
             result["band_correlation"] = bench_band_corr(ops, dev)
+            result["dr_spaam_forward"] = bench_dr_spaam(ops, synth, tab, dev)
             # PMC traffic of the same shapes (the profile run executes this very function)
             result["cutout"]["roofline"]["traffic"] = pmc_traffic(("cutout_",))[0]
             result["spatial_attention"]["roofline"]["traffic"] = pmc_traffic(("attn_",))[0]
@@ -367,6 +368,36 @@ def bench_attention(ops, dev):
     return {"workload": "spatial attention N=450 F=3584 E=128 w=11, batch %d" % B, "ms_per_call": ms,
             "roofline": {"bound": "hbm", "kernel": "attn_band_kernel + attn_merge_kernel<11>", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+def bench_dr_spaam(ops, synth, tab, dev):
+    """BASELINE configs[2]: 5-scan DROW windows -> cutout -> DR-SPAAM (SpatialDROW, random-init weights of
+    the reference architecture, eval mode): trunk on pof_conv3_bn_lrelu (float32 MFMA), gate on the HIP
+    attention, embedding GEMM and the two 1x1 heads on hipBLASLt / MIOpen through torch."""
+    import torch
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    B, T, N, P = 32, 5, N_PTS, 56
+    torch.manual_seed(3)
+    model = SpatialDROW(num_scans=T, num_pts=P, alpha=0.5, window_size=11, pedestrian_only=True).to(dev).eval()
+    model.fuse_for_inference()
+    sb = synth.make_batch(seed=3, B=B, T=T, N=N)
+    scans = torch.from_numpy(sb.scans).to(dev)
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=P,
+              padding_val=29.99, area_mode=True)
+
+    def step():
+        with torch.no_grad():
+            return model(ops.cutout(scans, tab, **kw))
+    ms = _time_kernel(torch, step, 5, warm=2)
+    # conv3 layers: 2 * L * 3 * Ci * Co per sequence; embedding GEMMs: 2 per gate step
+    seq_a = 2.0 * (56 * 3 * (1 * 64 + 64 * 64 + 64 * 128) + 28 * 3 * (128 * 128 * 2 + 128 * 256))
+    seq_c = 2.0 * (14 * 3 * (256 * 256 * 2 + 256 * 512) + 7 * 3 * (512 * 256 + 256 * 128))
+    flops = B * (N * T * seq_a + N * seq_c + (T - 1) * 2 * 2.0 * N * 3584 * 128)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"workload": "DR-SPAAM forward (cutout + SpatialDROW), %d windows of %d x %d-pt scans" % (B, T, N),
+            "ms_per_call": ms, "scans_per_s": B / (ms * 1e-3), "data": "synthetic scans, random-init weights",
+            "roofline": {"bound": "mfma", "kernel": "conv3_kernel<4> (float32 MFMA implicit GEMM)", "achieved": ach,
+                         "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}}
 
 
 def bench_band_corr(ops, dev):
