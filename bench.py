@@ -68,6 +68,8 @@ def parse():
     ap.add_argument("--no-chain", dest="chained", action="store_false",
                     help="two launches per step (params + streaming) instead of the chained single launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-model", action="store_true",
+                    help="skip the DR-SPAAM forward extra (PMC passes: keeps the per-kernel averages per shape)")
     ap.add_argument("--no-extra", action="store_true")
     return ap.parse_args()
 
@@ -307,7 +309,8 @@ def main():
             result["cutout"] = bench_cutout(ops, synth, tab, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
             result["band_correlation"] = bench_band_corr(ops, dev)
-            result["dr_spaam_forward"] = bench_dr_spaam(ops, synth, tab, dev)
+            if not a.no_model:
+                result["dr_spaam_forward"] = bench_dr_spaam(ops, synth, tab, dev)
             # PMC traffic of the same shapes (the profile run executes this very function)
             result["cutout"]["roofline"]["traffic"] = pmc_traffic(("cutout_",))[0]
             result["spatial_attention"]["roofline"]["traffic"] = pmc_traffic(("attn_",))[0]
