@@ -407,6 +407,22 @@ def main():
     gm["drow_x"], gm["drow_cls"], gm["drow_reg"] = xd.numpy(), dc.numpy(), dr_.numpy()
     np.savez_compressed(os.path.join(OUT, "dr_spaam_model.npz"), **gm)
 
+    # ---------------- N2: Prototype flow network (weights rebuilt from the seed) ----------------
+    from src.depracted.model import prototype as proto
+    gq = {}
+    torch.manual_seed(7)
+    pref = proto.Prototype(in_channel=1, max_displacement=5)
+    gq["keys"] = np.array(list(pref.state_dict().keys()))
+    gq["abs_sum"] = np.array([float(v.double().abs().sum()) for v in pref.state_dict().values()])
+    s1, s2 = torch.randn(3, 450, 1), torch.randn(3, 450, 1)
+    pref.eval()
+    with torch.no_grad():
+        gq["eval_out"] = pref(s1, s2).numpy()
+    pref.train()
+    gq["train_out"] = pref(s1, s2).detach().numpy()
+    gq["s1"], gq["s2"] = s1.numpy(), s2.numpy()
+    np.savez_compressed(os.path.join(OUT, "prototype_model.npz"), **gq)
+
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
 
