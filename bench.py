@@ -305,7 +305,7 @@ def main():
                          "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms},
         }
-        if not a.no_extra:
+        if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line
             result["cutout"] = bench_cutout(ops, synth, tab, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
             result["band_correlation"] = bench_band_corr(ops, dev)
