@@ -17,6 +17,7 @@
 //     load feeds 4 MFMAs; loads are issued a block of 8 k-steps ahead.
 //   * epilogue: y = acc * scale[co] + shift[co] (BatchNorm folded with the conv bias), LeakyReLU,
 //     optional max over position pairs (adjacent lanes), store.
+#include <algorithm>
 #include <type_traits>
 
 #include "pof_common.h"
@@ -203,20 +204,28 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
     if (S < 0 || Ci < 1 || Co < 1 || L < 1) return POF_E_BADARG;
     if (pool && (L < 2 || (L & 1))) return POF_E_SHAPE;   // pooled pairs sit on adjacent lanes: even L
     if (S == 0) return POF_OK;
-    ConvArgs a;
-    a.x = x; a.wt = wt; a.scale = scale; a.shift = shift; a.out = out;
-    a.S = S; a.Ci = Ci; a.Co = Co; a.L = L; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
-    if ((long long)S * Ci * L >= (1LL << 30)) return POF_E_SHAPE;   // 32-bit byte offsets per lane; callers chunk S
-    const long long ncol = (long long)S * L;
-    const long long tiles = (ncol + 31) / 32;
-    const long long gx = (tiles + kCvWaves - 1) / kCvWaves;
-    if (gx > 0x7fffffffLL) return POF_E_SHAPE;
+    // 32-bit byte offsets per lane inside one launch: sequences go in chunks of < 2^30 input elements
+    const long long per_seq = (long long)Ci * L;
+    if (per_seq >= (1LL << 30)) return POF_E_SHAPE;
+    const int s_max = (int)std::min<long long>(S, ((1LL << 30) - 1) / per_seq);
+    const int Lout = pool ? L / 2 : L;
     hipStream_t s = pof_stream(stream);
-    if (Co <= 64) {
-        conv3_kernel<2><<<dim3((unsigned)gx, (Co + 63) / 64), 64 * kCvWaves, 0, s>>>(a);
-    } else {
-        conv3_kernel<4><<<dim3((unsigned)gx, (Co + 127) / 128), 64 * kCvWaves, 0, s>>>(a);
+    for (int s0 = 0; s0 < S; s0 += s_max) {
+        ConvArgs a;
+        a.S = std::min(s_max, S - s0);
+        a.x = x + (long long)s0 * per_seq; a.wt = wt; a.scale = scale; a.shift = shift;
+        a.out = out + (long long)s0 * Co * Lout;
+        a.Ci = Ci; a.Co = Co; a.L = L; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
+        const long long ncol = (long long)a.S * L;
+        const long long tiles = (ncol + 31) / 32;
+        const long long gx = (tiles + kCvWaves - 1) / kCvWaves;
+        if (gx > 0x7fffffffLL) return POF_E_SHAPE;
+        if (Co <= 64) {
+            conv3_kernel<2><<<dim3((unsigned)gx, (Co + 63) / 64), 64 * kCvWaves, 0, s>>>(a);
+        } else {
+            conv3_kernel<4><<<dim3((unsigned)gx, (Co + 127) / 128), 64 * kCvWaves, 0, s>>>(a);
+        }
+        POF_CHECK_LAUNCH();
     }
-    POF_CHECK_LAUNCH();
     return POF_OK;
 }

@@ -682,3 +682,20 @@ def test_conv3_bn_lrelu_layer(ops, S, Ci, Co, L, pool):
     got = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, pool=pool)
     want = reference(x.double(), w.double(), scale.double(), shift.double()).float()
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_conv3_bn_lrelu_sequence_chunking(ops):
+    """More than 2^30 input elements: the entry point splits the sequences over several launches
+    (32-bit lane offsets inside one launch); sequences either side of the split match torch."""
+    S, Ci, Co, L = 150000, 512, 32, 14                       # 1.075e9 input elements, split at 149796
+    gen = torch.Generator(device=DEV).manual_seed(77)
+    x = torch.randint(-2, 3, (S, Ci, L), generator=gen, device=DEV, dtype=torch.int8).float()
+    w = torch.randint(-2, 3, (Co, Ci, 3), generator=gen, device=DEV, dtype=torch.int8).float()
+    scale = torch.full((Co,), 0.25, device=DEV)
+    shift = torch.zeros((Co,), device=DEV)
+    got = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, pool=True, negative_slope=0.125)
+    split = ((1 << 30) - 1) // (Ci * L)
+    for lo, hi in ((0, 40), (split - 40, split + 40), (S - 40, S)):
+        y = torch.nn.functional.conv1d(x[lo:hi].double(), w.double(), None, padding=1) * 0.25
+        want = torch.max_pool1d(torch.nn.functional.leaky_relu(y, 0.125), 2).float()
+        assert torch.equal(got[lo:hi], want), (lo, hi)
