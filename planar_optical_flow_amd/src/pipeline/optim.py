@@ -1,40 +1,34 @@
-"""Adam(amsgrad) + exponential-decay learning rate (reference src/pipeline/optim.py)."""
-from torch import optim
+"""Optimiser wrapper of the training pipeline (reference src/pipeline/optim.py): Adam with amsgrad,
+learning rate set once per epoch from an exponential-decay schedule given in the config as
+``scheduler_kwargs = {epoch0, lr0, epoch1, lr1}``."""
+import torch
 
 
-class _ExpDecayScheduler:
-    """lr0 until epoch0, geometric interpolation to lr1 at epoch1, lr1 afterwards."""
-
-    def __init__(self, epoch0, lr0, epoch1, lr1):
-        self.e0, self.e1, self.lr0, self.lr1 = epoch0, epoch1, lr0, lr1
-
-    def __call__(self, epoch):
-        if epoch < self.e0:
-            return self.lr0
-        if epoch > self.e1:
-            return self.lr1
-        return self.lr0 * (self.lr1 / self.lr0) ** ((epoch - self.e0) / (self.e1 - self.e0))
+def exp_decay_lr(epoch, epoch0, lr0, epoch1, lr1):
+    """lr0 up to epoch0, lr1 from epoch1 on, geometric interpolation in between."""
+    if epoch < epoch0:
+        return lr0
+    if epoch > epoch1:
+        return lr1
+    frac = (epoch - epoch0) / (epoch1 - epoch0)
+    return lr0 * (lr1 / lr0) ** frac
 
 
 class Optim:
+    # calls forwarded unchanged to the wrapped torch optimiser
+    _FORWARDED = ("zero_grad", "step", "state_dict", "load_state_dict")
+
     def __init__(self, model, cfg):
-        self._optim = optim.Adam(model.parameters(), amsgrad=True)
-        self._lr_scheduler = _ExpDecayScheduler(**cfg["scheduler_kwargs"])
+        self._schedule = dict(cfg["scheduler_kwargs"])
+        self._optim = torch.optim.Adam(model.parameters(), amsgrad=True)
 
-    def zero_grad(self):
-        self._optim.zero_grad()
-
-    def step(self):
-        self._optim.step()
-
-    def state_dict(self):
-        return self._optim.state_dict()
-
-    def load_state_dict(self, state_dict):
-        self._optim.load_state_dict(state_dict)
+    def __getattr__(self, name):
+        if name in Optim._FORWARDED:
+            return getattr(self.__dict__["_optim"], name)
+        raise AttributeError(name)
 
     def set_lr(self, epoch):
-        lr = self._lr_scheduler(epoch)
+        lr = exp_decay_lr(epoch, **self._schedule)
         for group in self._optim.param_groups:
             group["lr"] = lr
 

@@ -1,32 +1,45 @@
-"""``Pipeline(model, cfg)`` of the reference (src/pipeline/pipeline.py:6-36)."""
-from .logger import Logger
-from .optim import Optim
-from .trainer import Trainer
+"""Facade over logger + optimiser + trainer with the reference's constructor and method names
+(``Pipeline(model, cfg)``, reference src/pipeline/pipeline.py:6-36): the config sections
+``Logger`` / ``Optim`` / ``Trainer`` go to the three components, every phase is bracketed by
+debug-log lines, checkpoint helpers delegate to the logger."""
+from . import logger as _logger
+from . import optim as _optim
+from . import trainer as _trainer
 
 
 class Pipeline:
+    _PHASES = {"train": "Training", "evaluate": "Evaluation"}
+
     def __init__(self, model, cfg):
-        self.logger = Logger(cfg["Logger"])
-        self.optim = Optim(model, cfg["Optim"])
-        self.trainer = Trainer(self.logger, self.optim, cfg["Trainer"])
-        self.logger.log_debug("Pipeline starts.")
+        log = _logger.Logger(cfg["Logger"])
+        opt = _optim.Optim(model, cfg["Optim"])
+        self.logger, self.optim = log, opt
+        self.trainer = _trainer.Trainer(log, opt, cfg["Trainer"])
+        self._say("Pipeline starts.")
 
-    def close(self):
-        self.logger.log_debug("Pipeline closes.")
-        self.logger.close()
+    # ---- logging helpers ---------------------------------------------------------------
+    def _say(self, text):
+        self.logger.log_debug(text)
 
-    def train(self, model, train_loader, eval_loader=None):
-        """-> 0 when all epochs ran, 1 when interrupted (sigterm checkpoint written)."""
-        self.logger.log_debug("Training starts.")
-        status = self.trainer.train(model, train_loader, eval_loader)
-        self.logger.log_debug("Training ends (status %s)." % status)
+    def _phase(self, name, *args):
+        """Run ``trainer.<name>(*args)`` between 'starts' / 'ends (status ...)' debug lines; the status
+        is the trainer's: 0 when the phase completed, 1 when it was interrupted (sigterm checkpoint)."""
+        label = self._PHASES[name]
+        self._say(label + " starts.")
+        status = getattr(self.trainer, name)(*args)
+        self._say("{} ends (status {}).".format(label, status))
         return status
+
+    # ---- reference API -----------------------------------------------------------------
+    def train(self, model, train_loader, eval_loader=None):
+        return self._phase("train", model, train_loader, eval_loader)
 
     def evaluate(self, model, eval_loader, tb_prefix):
-        self.logger.log_debug("Evaluation starts.")
-        status = self.trainer.evaluate(model, eval_loader, tb_prefix)
-        self.logger.log_debug("Evaluation ends (status %s)." % status)
-        return status
+        return self._phase("evaluate", model, eval_loader, tb_prefix)
+
+    def close(self):
+        self._say("Pipeline closes.")
+        self.logger.close()
 
     def load_ckpt(self, model, ckpt):
         return self.logger.load_ckpt(ckpt, model, self.optim)
