@@ -34,3 +34,13 @@ class Optim:
 
     def get_lr(self):
         return self._optim.param_groups[0]["lr"]
+
+
+class _ExpDecayScheduler:
+    """Callable form of ``exp_decay_lr`` under the reference's name and constructor arguments."""
+
+    def __init__(self, epoch0, lr0, epoch1, lr1):
+        self._kw = dict(epoch0=epoch0, lr0=lr0, epoch1=epoch1, lr1=lr1)
+
+    def __call__(self, epoch):
+        return exp_decay_lr(epoch, **self._kw)
