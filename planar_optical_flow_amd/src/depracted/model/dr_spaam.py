@@ -144,7 +144,11 @@ class DROW(nn.Module):
         return self
 
     def _run_block(self, x, name, pool):
-        """One trunk block; pooled blocks pool after their last layer."""
+        """One trunk block; pooled blocks pool after their last layer.  Three routes:
+        eval + fuse_for_inference(): the HIP conv kernels (19 ms per B = 32 forward); eval without it on
+        the GPU: the channels-last GEMM form below (39 ms; MIOpen's inference path takes 234 ms on these
+        shapes); training and CPU: the plain torch modules (MIOpen's training-mode solvers are fine:
+        40 ms per fwd + bwd at B = 8 against 58 ms for the GEMM form)."""
         fused = getattr(self, "_fused", None)
         if fused is not None and not self.training and x.is_cuda and not torch.is_grad_enabled():
             out = x.contiguous().float()
@@ -152,8 +156,29 @@ class DROW(nn.Module):
             for i, (wt, scale, shift) in enumerate(layers):
                 out = ops.conv3_bn_lrelu(out, wt, scale, shift, pool=pool and i == len(layers) - 1)
             return out
+        if x.is_cuda and not self.training and getattr(self, "gemm_trunk", True):
+            return self._run_block_gemm(x, getattr(self, name), pool)
         out = getattr(self, name)(x)
         return torch.max_pool1d(out, kernel_size=2) if pool else out
+
+    @staticmethod
+    def _run_block_gemm(x, block, pool):
+        """conv3 + BatchNorm + LeakyReLU units as ONE large library GEMM each, channels last:
+        cols[S*L, 3*Ci] (the three taps side by side) x W[3*Ci, Co] (+ bias) -> [S*L, Co], then the unit's
+        own BatchNorm1d (2-D input: statistics over sequences and positions, as for [S, Co, L]) and
+        LeakyReLU.  MIOpen's inference path has no fast algorithm for 10^5 sequences of <= 56 points;
+        hipBLASLt runs these products near its float32 peak."""
+        S, Ci, L = x.shape
+        h = x.permute(0, 2, 1).contiguous()                                   # [S, L, Ci]
+        for unit in block:
+            conv, bn, act = unit[0], unit[1], unit[2]
+            hp = torch.nn.functional.pad(h, (0, 0, 1, 1))                     # zero rows at both ends of every sequence
+            cols = torch.cat((hp[:, 0:L], hp[:, 1:L + 1], hp[:, 2:L + 2]), dim=2).reshape(S * L, -1)
+            w = conv.weight.permute(2, 1, 0).reshape(-1, conv.out_channels)   # rows (tap, ci)
+            h = act(bn(torch.addmm(conv.bias, cols, w))).view(S, L, -1)
+        if pool:
+            h = h.view(S, L // 2, 2, h.shape[-1]).amax(dim=2)
+        return h.permute(0, 2, 1).contiguous()                                # [S, Co, L']
 
     def _forward_conv(self, x, conv_block):
         name = next(n for n in ("conv_block_1", "conv_block_2", "conv_block_3") if getattr(self, n) is conv_block)

@@ -23,6 +23,8 @@ def step():
     x = ops.cutout(scans, tab, **kw)
     with torch.no_grad():
         return m(x)
+if mode.startswith("train"):
+    step = lambda: None
 for _ in range(3): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()
@@ -30,3 +32,18 @@ for _ in range(5): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 print("DR-SPAAM forward B=%d [%s]: %.2f ms/step  %.0f scans/s" % (B, mode, dt * 1e3, B / dt), flush=True)
+if mode in ("train", "train-miopen"):
+    # one optimisation-style step: forward in training mode (BatchNorm batch statistics) + backward
+    m.train()
+    x = ops.cutout(scans, tab, **kw)
+    def tstep():
+        for p in m.parameters(): p.grad = None
+        pc, pr, ff = m(x)
+        (pc.sum() + pr.sum() + ff.sum()).backward()
+    for _ in range(2): tstep()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3): tstep()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 3
+    print("DR-SPAAM train step (fwd+bwd) B=%d [%s]: %.1f ms  peak mem %.1f GB" % (B, mode, dt * 1e3, torch.cuda.max_memory_allocated() / 1e9), flush=True)
