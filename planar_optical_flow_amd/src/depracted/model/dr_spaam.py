@@ -200,8 +200,14 @@ class DROW(nn.Module):
         B, N, C, P = x.shape
         out = self._forward_conv(x.reshape(B * N, C, P), self.conv_block_3)
         out = self._run_block(out, "conv_block_4", pool=False)
-        out = torch.nn.functional.avg_pool1d(out, kernel_size=out.shape[-1])
-        return self.conv_cls(out).view(B, N, -1), self.conv_reg(out).view(B, N, 2)
+        # average over the remaining positions, then the two 1x1 convolutions -- on a length-1 sequence
+        # they are dense layers: issue them as library GEMMs (MIOpen runs 1x1 convs on [B*N, 128, 1]
+        # through its naive kernel)
+        feat = out.mean(dim=-1)
+        lin = torch.nn.functional.linear
+        pred_cls = lin(feat, self.conv_cls.weight.squeeze(-1), self.conv_cls.bias)
+        pred_reg = lin(feat, self.conv_reg.weight.squeeze(-1), self.conv_reg.bias)
+        return pred_cls.view(B, N, -1), pred_reg.view(B, N, 2)
 
     def forward(self, x):
         return self._forward_fused_cutout(self._fuse_cutout(self._forward_cutout(x)))

@@ -51,6 +51,40 @@ def test_bad_arguments_are_rejected_without_launch(lib):
         _lib.call("pof_rotate_iou", None, None, None, 1, 1, 1, None, None, -1, 0, None)
 
 
+def test_every_entry_point_rejects_null_arguments(lib):
+    """Every int-returning device entry point called with all-NULL pointers and zero sizes returns a
+    negative status (no launch, no fault); the wrapper maps POF_E_BADARG to AssertionError."""
+    import ctypes as C
+    from planar_optical_flow_amd import _lib
+    skip = {"pof_abi_version", "pof_error_string", "pof_scan_preprocess_workspace_bytes", "pof_nms_workspace_bytes"}
+    for name, (restype, argtypes) in _lib.SIGNATURES.items():
+        if name in skip or restype is not C.c_int:
+            continue
+        args = []
+        for t in argtypes:
+            if t in (C.c_void_p, C.c_char_p) or (isinstance(t, type) and issubclass(t, C._Pointer)):
+                args.append(None)
+            elif t is C.c_double:
+                args.append(0.0)
+            else:
+                args.append(0)
+        rc = getattr(lib, name)(*args)
+        assert rc < 0, "%s accepted NULL arguments (rc=%d)" % (name, rc)
+
+
+def test_new_ops_refuse_cpu_tensors():
+    from planar_optical_flow_amd import ops
+    with pytest.raises(TypeError):
+        ops.polar_grid(torch.zeros(1, 2, 450))
+    with pytest.raises(TypeError):
+        ops.conv3_bn_lrelu(torch.zeros(2, 1, 56), torch.zeros(3, 1, 64), torch.ones(64), torch.zeros(64))
+    with pytest.raises(TypeError):
+        ops.segment_inputs(torch.zeros(10, 2, dtype=torch.float64), torch.zeros(1, 2, dtype=torch.float64),
+                           torch.zeros(1, dtype=torch.float64))
+    with pytest.raises(TypeError):
+        ops.band_correlation(torch.zeros(1, 4, 57), torch.zeros(1, 4, 57))
+
+
 def test_no_cpu_fallback():
     """The product path refuses CPU tensors instead of silently computing on the host."""
     from planar_optical_flow_amd import ops
