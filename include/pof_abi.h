@@ -238,6 +238,11 @@ int pof_flow_errors(const float *pred, const float *target, const float *mask, i
 int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C, int n,
                          int kernel_size, int max_disp, pof_stream_t stream);
 
+/* BASELINE config 5 ("fp16 correlation"): the same with float16 feature storage.  Products and
+ * accumulation are float32 (a float16 converts exactly), the output stays float32. */
+int pof_band_correlation_f16(const void *feat1_f16, const void *feat2_f16, float *out, int B, int C, int n,
+                             int kernel_size, int max_disp, pof_stream_t stream);
+
 /* Backward of pof_band_correlation (training Prototype end to end): given
  * g_out = dL/d out [B][D][n] returns dL/d feat1, dL/d feat2 [B][C][n].  n <= 512. */
 int pof_band_correlation_backward(const float *feat1, const float *feat2, const float *g_out,
@@ -255,6 +260,12 @@ int pof_band_correlation_backward(const float *feat1, const float *feat2, const 
 int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x, const float *tmpl,
                           int B, int N, int E, int F, int window, double alpha, float *band,
                           float *prob, float *out, pof_stream_t stream);
+
+/* Same with the large tensors (x, tmpl, out: [B][N][F]) stored as float16 and float32 arithmetic;
+ * the embeddings, band and prob stay float32.  Halves the traffic of the merge kernel. */
+int pof_spatial_attention_f16(const float *emb_x, const float *emb_t, const void *x_f16, const void *tmpl_f16,
+                              int B, int N, int E, int F, int window, double alpha, float *band, float *prob,
+                              void *out_f16, pof_stream_t stream);
 
 /* Backward of pof_spatial_attention (training SpatialDROW through the gate).
  * g_out = dL/d out [B][N][F]; g_band = dL/d band [B][N][w] or NULL.

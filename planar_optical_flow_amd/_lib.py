@@ -43,6 +43,8 @@ SIGNATURES = {
     "pof_nms_predicted_center": (_i, [_p, _p, _p, _p, _d, _i, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_flow_errors": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p]),
     "pof_band_correlation": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pof_band_correlation_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pof_spatial_attention_f16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "pof_band_correlation_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pof_spatial_attention_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
     "pof_spatial_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),

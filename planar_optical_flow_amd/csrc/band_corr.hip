@@ -33,8 +33,10 @@ constexpr int kPld = 65;     // LDS row stride of the staged 32 x 64 block of P
 
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
-template <int K>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const float *f1, const float *f2,
+// T = float or _Float16 (BASELINE config 5: float16 storage, float32 products and accumulation --
+// every float16 converts exactly, so the arithmetic after the load is the float32 kernel's).
+template <int K, typename T>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const T *f1, const T *f2,
                                                                         float *out, int B, int C, int n, int D,
                                                                         int nblk)
 {
@@ -52,8 +54,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const fl
     const int r = lane & 31, h = lane >> 5;
     // wave-uniform bases (scalar registers) + 32-bit per-lane offsets: global_load with an
     // SGPR base needs no 64-bit address VGPRs per load
-    const float *g1 = f1 + (long long)b * C * n;
-    const float *g2 = f2 + (long long)b * C * n;
+    const T *g1 = f1 + (long long)b * C * n;
+    const T *g2 = f2 + (long long)b * C * n;
     const int pa = ra + r, pb0 = cb + r, pb1 = cb + 32 + r;
     const bool va = pa >= 0 && pa < n, vb0 = pb0 >= 0 && pb0 < n, vb1 = pb1 >= 0 && pb1 < n;
     // clamped positions keep the masked lanes' (unused) loads inside the sample
@@ -76,10 +78,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const fl
             const int cp = min(cp0 + u, csteps - 1);
             // the upper half-wave of an odd last step would read channel C: it re-reads C-1 (zeroed below)
             const int ho = (odd_c && cp == csteps - 1) ? 0 : hoff;
-            const float *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
-            xa[set][u] = r1[la + ho];
-            x0[set][u] = r2[l0 + ho];
-            x1[set][u] = r2[l1 + ho];
+            const T *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
+            xa[set][u] = (float)r1[la + ho];
+            x0[set][u] = (float)r2[l0 + ho];
+            x1[set][u] = (float)r2[l1 + ho];
         }
     };
     auto mac_block = [&](int set, int cp0) {
@@ -137,8 +139,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void band_corr_kernel(const fl
 constexpr int kSmallWaves = 4;
 constexpr int kBandLd = 2 * (kMaxD / 2 + 2 * (kMaxK / 2)) + 2;   // 2 * 11 + 2: widest band, even stride
 
-template <int K>
-__global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const float *f1, const float *f2,
+template <int K, typename T>
+__global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const T *f1, const T *f2,
                                                                            float *out, int B, int C, int n, int D)
 {
     constexpr int HK = K / 2;
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const
     const int b = live ? b_raw : B - 1;
     const int MD = D / 2;
     const int r = lane & 31, h = lane >> 5;
-    const float *g1 = f1 + (long long)b * C * n;
-    const float *g2 = f2 + (long long)b * C * n;
+    const T *g1 = f1 + (long long)b * C * n;
+    const T *g2 = f2 + (long long)b * C * n;
     // pair start clamped into the row; which half of the loaded pair is the even position
     const int p = max(min(2 * r, n - 2), 0);
     const bool ve = 2 * r < n, vo = 2 * r + 1 < n;
@@ -169,10 +171,14 @@ __global__ __launch_bounds__(64 * kSmallWaves) void band_corr_small_kernel(const
         for (int u = 0; u < U; ++u) {
             const int cp = min(cp0 + u, csteps - 1);
             const int ho = (odd_c && cp == csteps - 1) ? 0 : hoff;
-            const float *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
-            // 4-byte aligned 8-byte loads (odd rows of an odd-n tensor start on a 4-byte boundary)
-            __builtin_memcpy(&xa[set][u], r1 + p + ho, 8);
-            __builtin_memcpy(&xb[set][u], r2 + p + ho, 8);
+            const T *r1 = g1 + cp * step, *r2 = g2 + cp * step;   // uniform
+            // element-aligned pair loads (odd rows of an odd-n tensor start on an element boundary)
+            using T2 = T __attribute__((ext_vector_type(2)));
+            T2 va, vb;
+            __builtin_memcpy(&va, r1 + p + ho, sizeof(T2));
+            __builtin_memcpy(&vb, r2 + p + ho, sizeof(T2));
+            xa[set][u] = F2{(float)va.x, (float)va.y};
+            xb[set][u] = F2{(float)vb.x, (float)vb.y};
         }
     };
     auto mac_block = [&](int set, int cp0) {
@@ -343,27 +349,25 @@ __global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const flo
     }
 }
 
-template <int K>
-void launch_k(const float *f1, const float *f2, float *out, int B, int C, int n, int D, hipStream_t s)
+template <int K, typename T>
+void launch_k(const T *f1, const T *f2, float *out, int B, int C, int n, int D, hipStream_t s)
 {
     if (n >= 2 && n <= 64) {
-        band_corr_small_kernel<K><<<(B + kSmallWaves - 1) / kSmallWaves, 64 * kSmallWaves, 0, s>>>(f1, f2, out, B, C,
-                                                                                                n, D);
+        band_corr_small_kernel<K, T><<<(B + kSmallWaves - 1) / kSmallWaves, 64 * kSmallWaves, 0, s>>>(f1, f2, out, B,
+                                                                                                   C, n, D);
         return;
     }
     constexpr int PTS = 32 - (K - 1);
     const int nblk = (n + PTS - 1) / PTS;
     const long long units = (long long)B * nblk;
     const unsigned grid = (unsigned)((units + kWavesPerBlock - 1) / kWavesPerBlock);
-    band_corr_kernel<K><<<grid, 64 * kWavesPerBlock, 0, s>>>(f1, f2, out, B, C, n, D, nblk);
+    band_corr_kernel<K, T><<<grid, 64 * kWavesPerBlock, 0, s>>>(f1, f2, out, B, C, n, D, nblk);
 }
 
-}  // namespace
-
-extern "C" int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C,
-                                    int n, int kernel_size, int max_disp, pof_stream_t stream)
+template <typename T>
+int band_corr_entry(const T *feat1, const T *feat2, float *out, int B, int C, int n, int kernel_size, int max_disp,
+                    pof_stream_t stream)
 {
-    POF_CLEAR_STALE_ERROR();
     if (!feat1 || !feat2 || !out || B < 0 || C < 1 || n < 1) return POF_E_BADARG;
     if (kernel_size < 1 || kernel_size > kMaxK || (kernel_size & 1) == 0) return POF_E_SHAPE;
     if (max_disp < 0 || 2 * max_disp + 1 > kMaxD) return POF_E_SHAPE;
@@ -372,12 +376,30 @@ extern "C" int pof_band_correlation(const float *feat1, const float *feat2, floa
     const int D = 2 * max_disp + 1;
     hipStream_t s = pof_stream(stream);
     switch (kernel_size) {
-        case 1: launch_k<1>(feat1, feat2, out, B, C, n, D, s); break;
-        case 3: launch_k<3>(feat1, feat2, out, B, C, n, D, s); break;
-        default: launch_k<5>(feat1, feat2, out, B, C, n, D, s); break;
+        case 1: launch_k<1, T>(feat1, feat2, out, B, C, n, D, s); break;
+        case 3: launch_k<3, T>(feat1, feat2, out, B, C, n, D, s); break;
+        default: launch_k<5, T>(feat1, feat2, out, B, C, n, D, s); break;
     }
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+
+}  // namespace
+
+extern "C" int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C,
+                                    int n, int kernel_size, int max_disp, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return band_corr_entry<float>(feat1, feat2, out, B, C, n, kernel_size, max_disp, stream);
+}
+
+extern "C" int pof_band_correlation_f16(const void *feat1_f16, const void *feat2_f16, float *out, int B, int C,
+                                        int n, int kernel_size, int max_disp, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return band_corr_entry<_Float16>(static_cast<const _Float16 *>(feat1_f16),
+                                     static_cast<const _Float16 *>(feat2_f16), out, B, C, n, kernel_size, max_disp,
+                                     stream);
 }
 
 extern "C" int pof_band_correlation_backward(const float *feat1, const float *feat2, const float *g_out,

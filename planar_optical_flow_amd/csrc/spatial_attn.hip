@@ -134,21 +134,32 @@ void launch_band(const float *emb_x, const float *emb_t, int B, int N, int E, fl
 //                out2[j] = alpha * g[j]                                          (d x)
 // x is read once and the outputs are written once: streaming loads / stores keep them from
 // evicting the template rows that neighbouring segments re-read from L2.
-using F4V = float __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void stream_store(float4 *p, const float4 &v)
+// Storage type T = float or _Float16 (BASELINE config 5: float16 storage, float32 arithmetic): a
+// lane owns 4 consecutive elements of a row (16 or 8 bytes) and computes on them as float4.
+template <typename T>
+using Col4 = T __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ float4 col_load(const Col4<T> *p)
 {
-    F4V t = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(t, reinterpret_cast<F4V *>(p));
+    const Col4<T> t = *p;
+    return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
 }
-__device__ __forceinline__ float4 stream_load(const float4 *p)
+template <typename T>
+__device__ __forceinline__ void stream_store(Col4<T> *p, const float4 &v)
 {
-    const F4V t = __builtin_nontemporal_load(reinterpret_cast<const F4V *>(p));
-    return make_float4(t.x, t.y, t.z, t.w);
+    Col4<T> t = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+    __builtin_nontemporal_store(t, p);
+}
+template <typename T>
+__device__ __forceinline__ float4 stream_load(const Col4<T> *p)
+{
+    const Col4<T> t = __builtin_nontemporal_load(p);
+    return make_float4((float)t.x, (float)t.y, (float)t.z, (float)t.w);
 }
 
-template <int W, bool TRANS>
-__global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const float4 *tmpl,
-                                                         const float *prob, float4 *out, float4 *out2,
+template <int W, bool TRANS, typename T>
+__global__ __launch_bounds__(128) void attn_merge_kernel(const Col4<T> *x, const Col4<T> *tmpl,
+                                                         const float *prob, Col4<T> *out, Col4<T> *out2,
                                                          int N, int F4, int L, float alpha,
                                                          float one_minus_alpha)
 {
@@ -159,10 +170,10 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
     const int s0 = blockIdx.y * L;
     const int s1 = min(N, s0 + L);
     const long long sample = (long long)b * N;
-    const float4 *T = tmpl + sample * F4 + col;
-    const float4 *X = TRANS ? T : x + sample * F4 + col;
-    float4 *O = out + sample * F4 + col;
-    float4 *O2 = TRANS ? out2 + sample * F4 + col : nullptr;
+    const Col4<T> *Tm = tmpl + sample * F4 + col;
+    const Col4<T> *X = TRANS ? Tm : x + sample * F4 + col;
+    Col4<T> *O = out + sample * F4 + col;
+    Col4<T> *O2 = TRANS ? out2 + sample * F4 + col : nullptr;
     const float *P = prob + sample * W;
     const int base = s0 - HW;
     const int rmax = s1 - 1 + HW;
@@ -175,7 +186,7 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
         for (int u = 0; u < W; ++u) {
             const int r = base + m * W + u;
             if (r <= rmax) {
-                win[u] = (r >= 0 && r <= N - 1) ? T[(long long)r * F4] : make_float4(0.f, 0.f, 0.f, 0.f);
+                win[u] = (r >= 0 && r <= N - 1) ? col_load<T>(Tm + (long long)r * F4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const int i = r - HW;
                 if (i >= s0) {
                     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -199,35 +210,35 @@ __global__ __launch_bounds__(128) void attn_merge_kernel(const float4 *x, const 
                         const float4 gv = win[(u + HW + 1) % W];  // row i itself
                         o = make_float4(one_minus_alpha * acc.x, one_minus_alpha * acc.y, one_minus_alpha * acc.z,
                                         one_minus_alpha * acc.w);
-                        stream_store(O2 + (long long)i * F4, make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w));
+                        stream_store<T>(O2 + (long long)i * F4, make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w));
                     } else {
-                        const float4 xv = stream_load(X + (long long)i * F4);
+                        const float4 xv = stream_load<T>(X + (long long)i * F4);
                         o.x = alpha * xv.x + one_minus_alpha * acc.x;
                         o.y = alpha * xv.y + one_minus_alpha * acc.y;
                         o.z = alpha * xv.z + one_minus_alpha * acc.z;
                         o.w = alpha * xv.w + one_minus_alpha * acc.w;
                     }
-                    stream_store(O + (long long)i * F4, o);
+                    stream_store<T>(O + (long long)i * F4, o);
                 }
             }
         }
     }
 }
 
-template <int W, bool TRANS>
-void launch_merge(const float *x, const float *tmpl, const float *prob, float *out, float *out2, int B, int N,
+template <int W, bool TRANS, typename T>
+void launch_merge(const T *x, const T *tmpl, const float *prob, T *out, T *out2, int B, int N,
                   int F, int L, double alpha, hipStream_t s)
 {
     const int F4 = F / 4;
     dim3 grid((F4 + 127) / 128, (N + L - 1) / L, B);
-    attn_merge_kernel<W, TRANS><<<grid, 128, 0, s>>>(
-        reinterpret_cast<const float4 *>(x), reinterpret_cast<const float4 *>(tmpl), prob,
-        reinterpret_cast<float4 *>(out), reinterpret_cast<float4 *>(out2), N, F4, L, (float)alpha,
+    attn_merge_kernel<W, TRANS, T><<<grid, 128, 0, s>>>(
+        reinterpret_cast<const Col4<T> *>(x), reinterpret_cast<const Col4<T> *>(tmpl), prob,
+        reinterpret_cast<Col4<T> *>(out), reinterpret_cast<Col4<T> *>(out2), N, F4, L, (float)alpha,
         (float)(1.0 - alpha));
 }
 
-template <bool TRANS>
-int dispatch_merge(int W, const float *x, const float *tmpl, const float *prob, float *out, float *out2, int B,
+template <bool TRANS, typename T>
+int dispatch_merge(int W, const T *x, const T *tmpl, const float *prob, T *out, T *out2, int B,
                    int N, int F, double alpha, hipStream_t s)
 {
     // segment length: whole scan per lane when the batch alone fills the chip,
@@ -236,14 +247,14 @@ int dispatch_merge(int W, const float *x, const float *tmpl, const float *prob, 
     int L = N;
     while (L > 32 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
     switch (W) {
-        case 1: launch_merge<1, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 3: launch_merge<3, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 5: launch_merge<5, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 7: launch_merge<7, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 9: launch_merge<9, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 11: launch_merge<11, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 13: launch_merge<13, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
-        case 15: launch_merge<15, TRANS>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 1: launch_merge<1, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 3: launch_merge<3, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 5: launch_merge<5, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 7: launch_merge<7, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 9: launch_merge<9, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 11: launch_merge<11, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 13: launch_merge<13, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
+        case 15: launch_merge<15, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
         default: return POF_E_SHAPE;
     }
     return POF_OK;
@@ -408,12 +419,11 @@ __global__ __launch_bounds__(256) void attn_demb_kernel(const float *emb_x, cons
 
 }  // namespace
 
-extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x,
-                                     const float *tmpl, int B, int N, int E, int F, int window,
-                                     double alpha, float *band, float *prob, float *out,
-                                     pof_stream_t stream)
+namespace {
+template <typename T>
+int attention_entry(const float *emb_x, const float *emb_t, const T *x, const T *tmpl, int B, int N, int E, int F,
+                    int window, double alpha, float *band, float *prob, T *out, pof_stream_t stream)
 {
-    POF_CLEAR_STALE_ERROR();
     if (!emb_x || !emb_t || !x || !tmpl || !prob || !out) return POF_E_BADARG;
     if (B < 0 || N < 1 || E < 1 || F < 1) return POF_E_BADARG;
     // the reference uses hw = int(window/2) neighbours each side: an even window
@@ -444,10 +454,31 @@ extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, con
         }
     }
     POF_CHECK_LAUNCH();
-    const int rc = dispatch_merge<false>(W, x, tmpl, prob, out, nullptr, B, N, F, alpha, s);
+    const int rc = dispatch_merge<false, T>(W, x, tmpl, prob, out, static_cast<T *>(nullptr), B, N, F, alpha, s);
     if (rc != POF_OK) return rc;
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+}  // namespace
+
+extern "C" int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x,
+                                     const float *tmpl, int B, int N, int E, int F, int window,
+                                     double alpha, float *band, float *prob, float *out,
+                                     pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return attention_entry<float>(emb_x, emb_t, x, tmpl, B, N, E, F, window, alpha, band, prob, out, stream);
+}
+
+extern "C" int pof_spatial_attention_f16(const float *emb_x, const float *emb_t, const void *x_f16,
+                                         const void *tmpl_f16, int B, int N, int E, int F, int window,
+                                         double alpha, float *band, float *prob, void *out_f16,
+                                         pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return attention_entry<_Float16>(emb_x, emb_t, static_cast<const _Float16 *>(x_f16),
+                                     static_cast<const _Float16 *>(tmpl_f16), B, N, E, F, window, alpha, band, prob,
+                                     static_cast<_Float16 *>(out_f16), stream);
 }
 
 extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const float *tmpl,
@@ -474,7 +505,7 @@ extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *e
     POF_CHECK_LAUNCH();
     attn_demb_kernel<<<dim3((N + 3) / 4, B), 256, 0, s>>>(emb_x, emb_t, dsim, N, E, W, d_emb_x, d_emb_t);
     POF_CHECK_LAUNCH();
-    const int rc = dispatch_merge<true>(W, nullptr, g_out, prob, d_tmpl, d_x, B, N, F, alpha, s);
+    const int rc = dispatch_merge<true, float>(W, static_cast<const float *>(nullptr), g_out, prob, d_tmpl, d_x, B, N, F, alpha, s);
     if (rc != POF_OK) return rc;
     POF_CHECK_LAUNCH();
     return POF_OK;

@@ -439,9 +439,11 @@ def flow_errors(pred, target, mask=None):
 
 
 def band_correlation(feat1, feat2, kernel_size=3, max_displacement=5, out=None):
-    """A9: [B,C,n] x2 float32 -> [B, 2*max_displacement+1, n] float32."""
-    feat1 = _dev(feat1, torch.float32, "feat1")
-    feat2 = _dev(feat2, torch.float32, "feat2")
+    """A9: [B,C,n] x2 float32 (or float16 storage, BASELINE config 5) -> [B, 2*max_displacement+1, n] float32."""
+    half = isinstance(feat1, torch.Tensor) and feat1.dtype == torch.float16
+    feat1 = _dev(feat1, torch.float16 if half else torch.float32, "feat1")
+    feat2 = _dev(feat2, torch.float16 if half else torch.float32, "feat2")
+    entry = "pof_band_correlation_f16" if half else "pof_band_correlation"
     if feat1.shape != feat2.shape or feat1.dim() != 3:
         raise ValueError("features must be two [B,C,n] tensors of equal shape")
     B, Cc, n = feat1.shape
@@ -452,18 +454,20 @@ def band_correlation(feat1, feat2, kernel_size=3, max_displacement=5, out=None):
         step = 65535
         for s in range(0, B, step):
             m = min(step, B - s)
-            _lib.call("pof_band_correlation", _ptr(feat1[s:s + m]), _ptr(feat2[s:s + m]), _ptr(out[s:s + m]),
+            _lib.call(entry, _ptr(feat1[s:s + m]), _ptr(feat2[s:s + m]), _ptr(out[s:s + m]),
                       m, Cc, n, int(kernel_size), int(max_displacement), _stream())
     return out
 
 
 def spatial_attention(emb_x, emb_t, x, tmpl, alpha=0.5, window_size=11, out=None):
-    """A10 after the embedding: emb_* [B,N,E], x/tmpl [B,N,...] float32 ->
-    (out like x, band [B,N,w], prob [B,N,w])."""
+    """A10 after the embedding: emb_* [B,N,E] float32, x/tmpl [B,N,...] float32 (or float16 storage,
+    BASELINE config 5) -> (out like x, band [B,N,w], prob [B,N,w])."""
     emb_x = _dev(emb_x, torch.float32, "emb_x")
     emb_t = _dev(emb_t, torch.float32, "emb_t")
-    x = _dev(x, torch.float32, "x")
-    tmpl = _dev(tmpl, torch.float32, "tmpl")
+    half = isinstance(x, torch.Tensor) and x.dtype == torch.float16
+    x = _dev(x, torch.float16 if half else torch.float32, "x")
+    tmpl = _dev(tmpl, torch.float16 if half else torch.float32, "tmpl")
+    entry = "pof_spatial_attention_f16" if half else "pof_spatial_attention"
     if emb_x.shape != emb_t.shape or emb_x.dim() != 3 or x.shape != tmpl.shape:
         raise ValueError("shape mismatch")
     B, N, E = emb_x.shape
@@ -480,7 +484,7 @@ def spatial_attention(emb_x, emb_t, x, tmpl, alpha=0.5, window_size=11, out=None
         step = 65535
         for s in range(0, B, step):
             m = min(step, B - s)
-            _lib.call("pof_spatial_attention", _ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]), _ptr(x[s:s + m]),
+            _lib.call(entry, _ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]), _ptr(x[s:s + m]),
                       _ptr(tmpl[s:s + m]), m, N, E, F, int(window_size), float(alpha), _ptr(band[s:s + m]),
                       _ptr(prob[s:s + m]), _ptr(out[s:s + m]), _stream())
     return out, band, prob

@@ -699,3 +699,41 @@ def test_conv3_bn_lrelu_sequence_chunking(ops):
         y = torch.nn.functional.conv1d(x[lo:hi].double(), w.double(), None, padding=1) * 0.25
         want = torch.max_pool1d(torch.nn.functional.leaky_relu(y, 0.125), 2).float()
         assert torch.equal(got[lo:hi], want), (lo, hi)
+
+
+# ---------------------------------------------------------------- BASELINE config 5: float16 storage
+@pytest.mark.parametrize("n", [5, 57, 64, 65, 450])
+def test_band_correlation_float16_storage(ops, n):
+    """float16 features, float32 products / accumulation: exact on integer data, and equal to the float32
+    kernel run on the same (float16-representable) values."""
+    rng = np.random.default_rng(300 + n)
+    for C, K, md in [(3, 3, 2), (37, 3, 5), (64, 5, 7)]:
+        f1 = rng.integers(-4, 5, (3, C, n)).astype(np.float16)
+        f2 = rng.integers(-4, 5, (3, C, n)).astype(np.float16)
+        out = ops.band_correlation(T(f1), T(f2), K, md)
+        ref = R.band_correlation(f1.astype(np.float64), f2.astype(np.float64), K, md)
+        assert out.dtype == torch.float32 and np.array_equal(out.cpu().numpy(), ref.astype(np.float32))
+    f1 = rng.normal(0, 1, (2, 40, n)).astype(np.float16)
+    f2 = rng.normal(0, 1, (2, 40, n)).astype(np.float16)
+    half = ops.band_correlation(T(f1), T(f2), 3, 5)
+    full = ops.band_correlation(T(f1.astype(np.float32)), T(f2.astype(np.float32)), 3, 5)
+    assert torch.equal(half, full)
+
+
+def test_spatial_attention_float16_storage(ops):
+    """x / tmpl / out stored as float16, float32 arithmetic: band and prob identical to the float32 call,
+    out = the float32 result of the same (float16-representable) inputs rounded once to float16."""
+    rng = np.random.default_rng(41)
+    B, N, E, F = 2, 450, 128, 3584
+    ex = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    et = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    x = rng.normal(0, 1, (B, N, F)).astype(np.float16)
+    t = rng.normal(0, 1, (B, N, F)).astype(np.float16)
+    oh, bh, ph = ops.spatial_attention(T(ex), T(et), T(x), T(t), 0.5, 11)
+    of, bf, pf = ops.spatial_attention(T(ex), T(et), T(x.astype(np.float32)), T(t.astype(np.float32)), 0.5, 11)
+    assert oh.dtype == torch.float16
+    assert torch.equal(bh, bf) and torch.equal(ph, pf)
+    assert torch.equal(oh, of.to(torch.float16))
+    wo, _ = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
+                                t.astype(np.float64), 0.5, 11)
+    np.testing.assert_allclose(oh.float().cpu().numpy(), wo, rtol=2e-3, atol=2e-3)

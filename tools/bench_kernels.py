@@ -83,3 +83,21 @@ if "polar" in which:
     ms = timeit(lambda: ops.polar_grid(scans, out=out))
     byt = B * Tn * N * 4 * 32
     print("polar grid B=%d T=%d: %.3f ms  %.0f GB/s" % (B, Tn, ms, byt / ms / 1e6))
+if "f16" in which:
+    for (B, C, n) in [(4096, 256, 57), (256, 256, 450)]:
+        f1 = torch.randn((B, C, n), device=dev).half(); f2 = torch.randn((B, C, n), device=dev).half()
+        out = torch.empty((B, 11, n), device=dev)
+        ms = timeit(lambda: ops.band_correlation(f1, f2, 3, 5, out=out), iters=10)
+        byt = B * (2 * C * n * 2 + 11 * n * 4)
+        print("corr f16 B=%d C=%d n=%d: %.3f ms  %.0f GB/s" % (B, C, n, ms, byt / ms / 1e6))
+    for B in (64, 256):
+        N, E, F = 450, 128, 3584
+        gen = torch.Generator(device=dev).manual_seed(10)
+        ex = torch.randn((B, N, E), device=dev, generator=gen) * 0.3
+        et = torch.randn((B, N, E), device=dev, generator=gen) * 0.3
+        x = torch.randn((B, N, F), device=dev, generator=gen).half()
+        t = torch.randn((B, N, F), device=dev, generator=gen).half()
+        out = torch.empty_like(x)
+        ms = timeit(lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), iters=10)
+        per = 3 * N * F * 2 + 2 * N * E * 4 + 2 * N * 11 * 4
+        print("attn f16 B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
