@@ -70,6 +70,17 @@ class DROWDeviceDataset:
         self.scans_t = torch.from_numpy(np.concatenate(scans_t)).to(dev)
         self.odoms = torch.from_numpy(np.concatenate(odoms)).to(dev)
         self.odoms_t = torch.from_numpy(np.concatenate(odoms_t)).to(dev)
+        # per-sample index tables and ALL annotations as one device CSR, built once: a batch is then
+        # gathered with index ops on the device instead of Python loops over its samples
+        seq = np.array([s[0] for s in self._samples])
+        self._s_seq_first = torch.from_numpy(np.asarray(self._seq_first, np.int32)[seq]).to(dev)
+        self._s_odom_lo = torch.from_numpy(np.asarray(self._odom_lo, np.int32)[seq]).to(dev)
+        self._s_odom_hi = torch.from_numpy(np.asarray(self._odom_hi, np.int32)[seq]).to(dev)
+        self._s_scan_idx = torch.from_numpy(np.array([s[1] for s in self._samples], np.int32)).to(dev)
+        all_dets = self.pre.make_detections([s[2] for s in self._samples], [s[3] for s in self._samples],
+                                            [s[4] for s in self._samples])
+        self._d_off = all_dets.offsets.to(torch.int64)
+        self._d_rphi, self._d_cls = all_dets.rphi, all_dets.cls
 
     @classmethod
     def from_files(cls, data_path, split="train", max_sequences=5, **kw):
@@ -83,6 +94,19 @@ class DROWDeviceDataset:
     def from_pack(cls, path, **kw):
         from . import drow_io
         return cls(drow_io.load_pack(path), **kw)
+
+    def _gather_detections(self, idx):
+        """CSR of the batch's samples from the data set's CSR (device index arithmetic only)."""
+        start = self._d_off[idx]
+        cnt = self._d_off[idx + 1] - start
+        offs = torch.zeros(idx.numel() + 1, dtype=torch.int64, device=self.device)
+        torch.cumsum(cnt, 0, out=offs[1:])
+        total = int(offs[-1])                      # the one host sync of the batch
+        if total == 0:
+            return ops.DetCSR(offs.to(torch.int32), self._d_rphi[:1].clone(), self._d_cls[:1].clone())
+        owner = torch.repeat_interleave(torch.arange(idx.numel(), device=self.device), cnt, output_size=total)
+        rows = start[owner] + (torch.arange(total, device=self.device) - offs[owner])
+        return ops.DetCSR(offs.to(torch.int32), self._d_rphi[rows].contiguous(), self._d_cls[rows].contiguous())
 
     def __len__(self):
         return len(self._samples)
@@ -99,16 +123,14 @@ class DROWDeviceDataset:
         the annotation keys."""
         smp = [self._samples[i] for i in indices]
         dev = self.device
-        seq = np.array([s[0] for s in smp])
-        seq_first = torch.from_numpy(np.asarray(self._seq_first, np.int32)[seq]).to(dev)
-        odom_lo = torch.from_numpy(np.asarray(self._odom_lo, np.int32)[seq]).to(dev)
-        odom_hi = torch.from_numpy(np.asarray(self._odom_hi, np.int32)[seq]).to(dev)
-        scan_idx = torch.from_numpy(np.array([s[1] for s in smp], np.int32)).to(dev)
+        idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=dev)
+        seq_first, odom_lo, odom_hi = self._s_seq_first[idx], self._s_odom_lo[idx], self._s_odom_hi[idx]
+        scan_idx = self._s_scan_idx[idx]
         windows, row_cur, row_prev = ops.gather_windows(self.scans, seq_first, scan_idx, self.num_scans,
                                                         self.distance, self.scan_stride)
         odom0, odom1, _, idx1 = ops.associate_odometry(self.scans_t, self.odoms_t, self.odoms, odom_lo, odom_hi,
                                                        row_cur, row_prev)
-        dets = self.pre.make_detections([s[2] for s in smp], [s[3] for s in smp], [s[4] for s in smp])
+        dets = self._gather_detections(idx)
         batch = self.pre(windows, odom0, odom1, dets)
         batch["odom0"] = odom0
         batch["dets_wc"] = [s[2] for s in smp]
