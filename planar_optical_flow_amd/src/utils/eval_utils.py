@@ -26,3 +26,45 @@ def flow_epe(pred, target, mask=None):
     m = None if mask is None else _as_dev_f32(mask)
     e, _, c = ops.flow_errors(p, t, m)
     return (e.sum() / c.sum()).item()
+
+
+# ---------------------------------------------------------------------------------------
+# batch -> model -> loss adapters (reference :10-29, :90-127, :136-155).  They accept the
+# reference's NumPy batch dicts as well as the device batches of DROWDeviceDataset /
+# DROWBatchPreprocessor (no host round trip then).
+# ---------------------------------------------------------------------------------------
+def model_fn(model, batch):
+    """Prototype flow network on scan pairs: batch['scan_pair'] [B, 2, N, C], batch['flow_target_flow']."""
+    pair = batch["scan_pair"]
+    scan1, scan2 = _as_dev_f32(pair[:, 0]), _as_dev_f32(pair[:, 1])
+    pred_flow = model(scan1, scan2)
+    return model.loss_fn(pred_flow, _as_dev_f32(batch["flow_target_flow"]))[0]
+
+
+def model_fn_dr_spaam(model, batch):
+    """FlowDROW_pretrained step -> (masked flow loss, mean |pred| and mean |target| over the kept points)."""
+    cur_scan = _as_dev_f32(batch["scans"][:, -1])
+    target, mask = _as_dev_f32(batch["target_flow"]), _as_dev_f32(batch["exclude_mask"])
+    _, _, pred_flow = model(_as_dev_f32(batch["input"]), cur_scan)
+    loss = model.loss_fn(pred_flow, target, mask=mask)
+    keep = mask == 1.0
+    return loss, torch.norm(pred_flow, dim=-1)[keep].mean(), torch.norm(target, dim=-1)[keep].mean()
+
+
+def model_fn_Bb_regression(model, batch):
+    """Box head step: the loss is on the box parameters after the centre, target[:, 2:]."""
+    pred = model(_as_dev_f32(batch["input"]))
+    return model.loss_fn(pred, _as_dev_f32(batch["target"])[:, 2:])
+
+
+def model_fn_eval(model, eval_loader):
+    """-> (mean EPE, mean AAE in degrees) over the loader, per-batch means averaged like the reference."""
+    epe = aae = 0.0
+    with torch.no_grad():
+        for batch in eval_loader:
+            _, _, pred_flow = model(_as_dev_f32(batch["input"]), _as_dev_f32(batch["scans"][:, -1]))
+            e, a = loss_fn_eval(pred_flow, batch["target_flow"])
+            epe += e.mean().item()
+            aae += a.mean().item()
+    n = len(eval_loader)
+    return epe / n, aae / n

@@ -453,3 +453,40 @@ def test_prototype_forward_equals_reference(golden):
     loss, err = m.loss_fn(out, torch.zeros_like(out))
     loss.backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_model_fn_adapters_on_device_batches(golden):
+    """The reference's batch -> model -> loss adapters on device batches: a FlowDROW-style model fed by the
+    device data set trains one step; NumPy batches give the same loss."""
+    from dataset_fixture import CUTOUT_KW, load_sequences
+    from planar_optical_flow_amd.scan_store import DROWDeviceDataset
+    from planar_optical_flow_amd.src.utils import eval_utils as eu
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW, flow_loss
+
+    class FlowHead(torch.nn.Module):          # SpatialDROW + a per-point flow head (FlowDROW needs n_cutout == window)
+        def __init__(self):
+            super().__init__()
+            self.net = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+            self.head = torch.nn.Linear(12, 2)
+            self.loss_fn = flow_loss
+
+        def forward(self, x, cur_scan):
+            pc, pr, ff = self.net(x)
+            return pc, pr, self.head(torch.cat((ff, cur_scan.unsqueeze(-1)), dim=-1))
+
+    g = golden("dataset_items")
+    ds = DROWDeviceDataset(load_sequences(g), num_scans=5, cutout_kwargs=CUTOUT_KW, drop_static=False)
+    batch = ds.get_batch(list(range(6)))
+    torch.manual_seed(0)
+    model = FlowHead().cuda().train()
+    loss, pn, tn = eu.model_fn_dr_spaam(model, batch)
+    loss.backward()
+    assert torch.isfinite(loss) and model.head.weight.grad is not None
+    np_batch = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in batch.items()}
+    model.eval()
+    with torch.no_grad():
+        l_dev = eu.model_fn_dr_spaam(model, batch)[0].item()
+        l_np = eu.model_fn_dr_spaam(model, np_batch)[0].item()
+    assert abs(l_dev - l_np) < 1e-6
+    epe, aae = eu.model_fn_eval(model, [batch, batch])
+    assert np.isfinite(epe) and np.isfinite(aae)
