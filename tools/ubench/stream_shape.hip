@@ -39,6 +39,34 @@ __global__ __launch_bounds__(256) void shape_kernel(const float *r, float *flow,
     }
 }
 
+// 4 points per lane (113 active lanes of a 128-thread workgroup), streaming stores
+__global__ __launch_bounds__(128) void shape4_kernel(const float *r, float *flow, long long *cls, float *reg, float *mask, int B)
+{
+    const int b = blockIdx.x;
+    const int p = threadIdx.x;            // group of 4 points
+    if (4 * p >= N) return;
+    const bool full = 4 * p + 3 < N;      // N = 450: the last group has 2 points
+    using F4 = float __attribute__((ext_vector_type(4)));
+    using L2 = long long __attribute__((ext_vector_type(2)));
+    const float *row = r + (long long)b * N + 4 * p;
+    const float v0 = row[0], v1 = row[1], v2 = full ? row[2] : 0.f, v3 = full ? row[3] : 0.f;
+    F4 *fo = reinterpret_cast<F4 *>(flow + (long long)b * N * 2) + 2 * p;
+    F4 *ro = reinterpret_cast<F4 *>(reg + (long long)b * N * 2) + 2 * p;
+    L2 *co = reinterpret_cast<L2 *>(cls + (long long)b * N) + 2 * p;
+    float *mo = mask + (long long)b * N + 4 * p;
+    __builtin_nontemporal_store(F4{v0, v1, v0 + 1.f, v1 + 1.f}, fo);
+    __builtin_nontemporal_store(F4{v0, v1, v0 + 1.f, v1 + 1.f}, ro);
+    __builtin_nontemporal_store(L2{v0 > 3.f, v1 > 3.f}, co);
+    using F2 = float __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(F2{v0, v1}, reinterpret_cast<F2 *>(mo));
+    if (full) {
+        __builtin_nontemporal_store(F4{v2, v3, v2 + 1.f, v3 + 1.f}, fo + 1);
+        __builtin_nontemporal_store(F4{v2, v3, v2 + 1.f, v3 + 1.f}, ro + 1);
+        __builtin_nontemporal_store(L2{v2 > 3.f, v3 > 3.f}, co + 1);
+        __builtin_nontemporal_store(F2{v2, v3}, reinterpret_cast<F2 *>(mo) + 1);
+    }
+}
+
 // flat grid-stride copy-like kernel: same bytes, ideal access pattern
 __global__ __launch_bounds__(256) void flat_kernel(const float4 *in, float4 *out, long long n_in, long long n_out)
 {
@@ -74,6 +102,8 @@ int main()
     run("shape SPB=1", [&](int k) { shape_kernel<1, false><<<B, 256>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
     run("shape SPB=2", [&](int k) { shape_kernel<2, false><<<B / 2, 256>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
     run("shape SPB=4", [&](int k) { shape_kernel<4, false><<<B / 4, 256>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
+    run("shape 4 pts/lane nontemporal", [&](int k) { shape4_kernel<<<B, 128>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
+    run("shape SPB=1 nontemporal", [&](int k) { shape_kernel<1, true><<<B, 256>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
     run("shape SPB=2 nontemporal", [&](int k) { shape_kernel<2, true><<<B / 2, 256>>>(r[k], flow[k], cls[k], reg[k], mask[k], B); });
     // flat: read 4N*B from r, write 28N*B into flow+reg+cls region (use flow/reg/cls as one? separate allocs: write cls+flow+reg sizes)
     for (int g : {1024, 2048, 4096, 8192}) {
