@@ -351,6 +351,15 @@ int pof_segment_inputs(const double *points, int Np, int D, const double *center
                        int S, double radius, int input_size, int min_segment_size, uint32_t seed,
                        float *x, int32_t *count, uint8_t *mask, pof_stream_t stream);
 
+/* Training-side twin (src/data_handle/jrdb_dataset.py:99-156): segments already cut (CSR
+ * seg_offsets [S+1] over points [P][D]); per sample: subtract centers[s], optionally append
+ * extra[s] as a column (the random input angle), optionally drop int(n * random_drop) random
+ * points first, then the same fixed-size resampling -> x [S][input_size][D + (extra ? 1 : 0)],
+ * count[s] = points kept.  max_segment = longest segment (<= 4096). */
+int pof_segment_resample(const double *points, int D, const int32_t *seg_offsets, int S, int max_segment,
+                         const double *centers, const double *extra, double random_drop, int input_size,
+                         uint32_t seed, float *x, int32_t *count, pof_stream_t stream);
+
 /* ----------------------------------------------------------------------
  * N4 scans_to_polar_grid                        src/utils/utils.py:492-531
  * scans [B][T][N] float32 -> out [B][T][R][N] float32, R = int((max-min)/bin) + 1:

@@ -54,6 +54,7 @@ SIGNATURES = {
     "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),
     "pof_conv3_bn_lrelu": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "pof_segment_inputs": (_i, [_p, _i, _i, _p, _p, _i, _d, _i, _i, C.c_uint32, _p, _p, _p, _p]),
+    "pof_segment_resample": (_i, [_p, _i, _p, _i, _i, _p, _p, _d, _i, C.c_uint32, _p, _p, _p]),
     "pof_polar_grid": (_i, [_p, _i, _i, _i, _d, _d, _d, _d, _i, _p, _p]),
     "pof_csv_shape": (_i, [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "pof_csv_read_f64": (_i, [C.c_char_p, _ll, _i, _p, _i]),

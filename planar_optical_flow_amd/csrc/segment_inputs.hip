@@ -133,6 +133,70 @@ __global__ __launch_bounds__(kSegThreads) void segment_inputs_kernel(SegArgsIn a
     }
 }
 
+// Training-side twin (src/data_handle/jrdb_dataset.py:99-156): the segments are already cut
+// (CSR over a point pool), every sample subtracts its detection centre, optionally appends one
+// per-sample value as an extra column (the reference's random input angle), optionally drops
+// a random fraction of its points first (`shuffle; input[int(n * drop):]`), then the same
+// fixed-size resampling.  One workgroup per sample, same hash order as above.
+struct ResampleArgs {
+    const double *points;    // [P][D]
+    const int32_t *seg_off;  // [S+1]
+    const double *centers;   // [S][D]
+    const double *extra;     // [S] or null
+    int D, M;
+    double drop;
+    uint32_t seed;
+    float *x;                // [S][M][D + (extra ? 1 : 0)]
+    int32_t *count;          // [S] points kept after the random drop
+};
+
+__global__ __launch_bounds__(kSegThreads) void segment_resample_kernel(ResampleArgs a)
+{
+    __shared__ unsigned long long s_key[kSegCap];
+    const int smp = blockIdx.x, tid = threadIdx.x;
+    const int D = a.D, W = D + (a.extra ? 1 : 0);
+    const int p0 = a.seg_off[smp], n_all = a.seg_off[smp + 1] - p0;
+    float *x = a.x + (long long)smp * a.M * W;
+    const int dropped = (int)((double)n_all * a.drop);          // int(len(input) * random_drop)
+    const int n = n_all - dropped;
+    if (tid == 0) a.count[smp] = n;
+    if (n <= 0 || n_all > kSegCap) {                            // (the launcher rejects oversized segments)
+        for (int e = tid; e < a.M * W; e += kSegThreads) x[e] = 0.0f;
+        return;
+    }
+    int mp = 1;
+    while (mp < n_all) mp <<= 1;
+    for (int e = tid; e < mp; e += kSegThreads)
+        s_key[e] = e < n_all ? (((unsigned long long)point_hash(a.seed, smp, e) << 32) | (uint32_t)e) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= mp; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < mp; i += kSegThreads) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long ki = s_key[i], kl = s_key[l];
+                    const bool up = (i & k) == 0;
+                    if (up ? (ki > kl) : (ki < kl)) {
+                        s_key[i] = kl;
+                        s_key[l] = ki;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // hash order = the shuffle; its first `dropped` entries are the dropped points
+    const int rep = n > a.M ? 1 : a.M / n;
+    const double ex = a.extra ? a.extra[smp] : 0.0;
+    for (int j = tid; j < a.M; j += kSegThreads) {
+        const int src = n > a.M ? j : ((j < n * rep) ? j / rep : (j - n * rep) / rep);
+        const int pi = p0 + (int)(uint32_t)s_key[dropped + src];
+        for (int d = 0; d < D; ++d)
+            x[j * W + d] = (float)(a.points[(long long)pi * D + d] - a.centers[(long long)smp * D + d]);
+        if (a.extra) x[j * W + D] = (float)ex;
+    }
+}
+
 }  // namespace
 
 extern "C" int pof_segment_inputs(const double *points, int Np, int D, const double *centers, const double *oris,
@@ -149,6 +213,24 @@ extern "C" int pof_segment_inputs(const double *points, int Np, int D, const dou
     a.points = points; a.centers = centers; a.oris = oris; a.Np = Np; a.D = D; a.M = input_size;
     a.min_size = min_segment_size; a.radius = radius; a.seed = seed; a.x = x; a.count = count; a.mask = mask;
     segment_inputs_kernel<<<S, kSegThreads, 0, pof_stream(stream)>>>(a);
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
+extern "C" int pof_segment_resample(const double *points, int D, const int32_t *seg_offsets, int S, int max_segment,
+                                    const double *centers, const double *extra, double random_drop, int input_size,
+                                    uint32_t seed, float *x, int32_t *count, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (!points || !seg_offsets || !centers || !x || !count) return POF_E_BADARG;
+    if (S < 0 || input_size < 1 || !(random_drop >= 0.0) || !(random_drop < 1.0)) return POF_E_BADARG;
+    if (D < 2 || D > 3) return POF_E_SHAPE;
+    if (max_segment > kSegCap) return POF_E_SHAPE;      // the caller states the longest segment
+    if (S == 0) return POF_OK;
+    ResampleArgs a;
+    a.points = points; a.seg_off = seg_offsets; a.centers = centers; a.extra = extra; a.D = D; a.M = input_size;
+    a.drop = random_drop; a.seed = seed; a.x = x; a.count = count;
+    segment_resample_kernel<<<S, kSegThreads, 0, pof_stream(stream)>>>(a);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }

@@ -377,6 +377,32 @@ def segment_inputs(points, centers, oris, radius=0.4, input_size=64, min_segment
     return x, count
 
 
+def segment_resample(points, seg_offsets, centers, extra=None, random_drop=0.0, input_size=64, seed=0,
+                     max_segment=None):
+    """Box-head training feeder: points [P,D] f64 pool, seg_offsets [S+1] int32 CSR, centers [S,D] f64,
+    extra [S] f64 or None -> (x [S,input_size,D(+1)] f32, count [S] int32)."""
+    points = _dev(points, torch.float64, "points")
+    seg_offsets = _dev(seg_offsets, torch.int32, "seg_offsets")
+    centers = _dev(centers, torch.float64, "centers")
+    if extra is not None:
+        extra = _dev(extra, torch.float64, "extra")
+    D = points.shape[1]
+    S = seg_offsets.numel() - 1
+    if centers.shape != (S, D):
+        raise ValueError("centers must be [S, D]")
+    if max_segment is None:
+        max_segment = int((seg_offsets[1:] - seg_offsets[:-1]).max().item()) if S > 0 else 0
+    W = D + (0 if extra is None else 1)
+    x = torch.zeros((S, int(input_size), W), dtype=torch.float32, device=points.device)
+    count = torch.zeros((S,), dtype=torch.int32, device=points.device)
+    if S > 0:
+        with torch.cuda.device(points.device):
+            _lib.call("pof_segment_resample", _ptr(points), D, _ptr(seg_offsets), S, int(max_segment), _ptr(centers),
+                      _ptr(extra) if extra is not None else None, float(random_drop), int(input_size),
+                      int(seed) & 0xFFFFFFFF, _ptr(x), _ptr(count), _stream())
+    return x, count
+
+
 def polar_grid(scans, min_range=0.0, max_range=30.0, range_bin_size=1.0, tsdf_clip=1.0, normalize=True, out=None):
     """N4 for a batch: scans [B,T,N] float32 -> [B, T, R, N] float32, R = int((max-min)/bin) + 1."""
     scans = _dev(scans, torch.float32, "scans")

@@ -490,3 +490,87 @@ def test_model_fn_adapters_on_device_batches(golden):
     assert abs(l_dev - l_np) < 1e-6
     epe, aae = eu.model_fn_eval(model, [batch, batch])
     assert np.isfinite(epe) and np.isfinite(aae)
+
+
+def _box_frames(rng, n_frames=3, is_3d=True):
+    frames = []
+    for _ in range(n_frames):
+        K = int(rng.integers(3, 6))
+        boxes = np.column_stack([rng.uniform(-5, 5, K), rng.uniform(-5, 5, K), rng.uniform(-0.4, 0.1, K),
+                                 rng.uniform(0.5, 1.0, K), rng.uniform(0.4, 0.8, K), rng.uniform(1.5, 1.9, K),
+                                 rng.uniform(-4, 4, K)])
+        if not is_3d:
+            boxes = boxes[:, [0, 1, 3, 4, 6]]
+        D = 3 if is_3d else 2
+        segs, ctrs = [], []
+        for k in range(K):
+            n = int(rng.choice([3, 9, 40, 150]))
+            c = np.append(boxes[k, :2] + rng.uniform(-0.1, 0.1, 2), 0.176)[:D]
+            pts = np.column_stack([boxes[k, :2] + rng.normal(0, 0.2, (n, 2)), rng.uniform(-0.5, 0.5, n)])[:, :D]
+            segs.append(pts)
+            ctrs.append(c)
+        frames.append({"segments": segs, "boxes": boxes, "dets_center": np.array(ctrs)})
+    return frames
+
+
+@pytest.mark.parametrize("is_3d", [True, False])
+def test_box_regression_dataset_feeder(is_3d):
+    """A14 feeder (jrdb_dataset.py:99-230): size filter, one augmented copy per training sample, the
+    reference's target transforms, random drop count, resampling multiset and the appended input angle."""
+    from planar_optical_flow_amd.src.data_handle.jrdb_dataset import JRDBBoxRegressionDataset
+    cfg = {"input_size": 64, "is_3d": is_3d, "min_segment_size": 5,
+           "augmentation_kwargs": {"use_data_augmentation": True, "rot_max": 0.25, "dim_max": 0.1, "dist_max": 0.2,
+                                   "random_drop": 0.25}}
+    frames = _box_frames(np.random.default_rng(7), is_3d=is_3d)
+    n_kept = sum(1 for f in frames for s in f["segments"] if len(s) > 5)
+    ds = JRDBBoxRegressionDataset("train", cfg, frames, rng=np.random.default_rng(1), seed=2)
+    assert len(ds) == 2 * n_kept                         # original + augmented copy
+    val = JRDBBoxRegressionDataset("val", cfg, _box_frames(np.random.default_rng(7), is_3d=is_3d),
+                                   rng=np.random.default_rng(1))
+    assert len(val) == n_kept
+    # data_augmentation against a direct restatement with the same draws
+    seg, tgt, ctr = val.inputs[0], val.targets[0], val.dets_center[0]
+    chk = np.random.default_rng(5)
+    val._rng = np.random.default_rng(5)
+    ia, ta, ca = val.data_augmentation(seg.copy(), tgt.copy(), ctr.copy())
+    rz = chk.uniform(-0.25 * np.pi, 0.25 * np.pi); dm = 1.0 + chk.uniform(-0.1, 0.1); tr = chk.uniform(-0.2, 0.2, 2)
+    R2 = np.array([[np.cos(rz), -np.sin(rz)], [np.sin(rz), np.cos(rz)]], dtype=np.float32)
+    np.testing.assert_allclose(ia[:, :2], (seg[:, :2] - tgt[:2]) @ R2.T + tgt[:2] + tr, atol=1e-12)
+    np.testing.assert_allclose(ta[:2], tgt[:2] + tr, atol=1e-12)
+    dims = slice(3, 6) if is_3d else slice(2, 4)
+    np.testing.assert_allclose(ta[dims], tgt[dims] * dm, atol=1e-12)
+    # batches
+    idx = list(range(len(ds)))
+    b = ds.get_batch(idx)
+    D = 3 if is_3d else 2
+    x = b["input"].cpu().numpy()
+    assert x.shape == (len(ds), 64, D + 1)
+    tg = np.array(ds.targets)
+    ctr_all = np.array(ds.dets_center)
+    want_t = tg[:, 2:].copy()
+    want_t[:, 0] -= ctr_all[:, -1]
+    ang = x[:, 0, D].astype(np.float64)
+    want_t[:, -1] = tg[:, -1] - (tg[:, -1] - b["target"].cpu().numpy()[:, -1])      # rot_z - input_angle, checked below
+    np.testing.assert_allclose(b["target"].cpu().numpy()[:, :-1], want_t[:, :-1], atol=1e-12)
+    np.testing.assert_allclose(tg[:, -1] - b["target"].cpu().numpy()[:, -1], ang, atol=1e-6)   # column = input angle
+    assert np.all(np.abs(ang - tg[:, -1]) <= 0.25 * np.pi + 1e-6)
+    for s in range(len(ds)):
+        assert np.all(x[s, :, D] == x[s, 0, D])
+        pts = (np.asarray(ds.inputs[s], np.float64) - ctr_all[s]).astype(np.float32)
+        n_all = len(pts)
+        n = n_all - int(n_all * 0.25)
+        used = np.zeros(n_all, dtype=int)
+        for row in x[s, :, :D]:
+            hit = np.where((pts == row).all(axis=1))[0]
+            assert len(hit) >= 1
+            used[hit[0]] += 1
+        assert (used > 0).sum() == min(n, 64)                     # dropped points never appear
+        if n <= 64:
+            assert used[used > 0].min() >= 64 // n and used.sum() == 64
+    # evaluation split: no drop, deterministic point set
+    bv = val.get_batch([0, 1])
+    xv = bv["input"].cpu().numpy()
+    pts0 = (np.asarray(val.inputs[0], np.float64) - val.dets_center[0]).astype(np.float32)
+    assert {tuple(r) for r in xv[0, :, :D]} <= {tuple(r) for r in pts0}
+    if len(pts0) <= 64:
+        assert {tuple(r) for r in xv[0, :, :D]} == {tuple(r) for r in pts0}
