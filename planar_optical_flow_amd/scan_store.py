@@ -30,7 +30,7 @@ class DROWDeviceDataset:
         self.device = torch.device(device)
         self.pre = DROWBatchPreprocessor(cutout_kwargs=cutout_kwargs, pedestrian_only=pedestrian_only,
                                          device=device)
-        scans, scans_t, odoms, odoms_t = [], [], [], []
+        scans, scans_t, odoms, odoms_t, scans_ns_all = [], [], [], [], []
         self._seq_first, self._odom_lo, self._odom_hi = [], [], []
         self._samples = []  # (sequence, scan index in sequence, wc, wa, wp)
         self.seq_names = []  # sequences that survived the static-scene filter (reference: self.seq_names)
@@ -53,6 +53,7 @@ class DROWDeviceDataset:
             self._odom_lo.append(odom0)
             self._odom_hi.append(odom0 + len(od))
             scans.append(sc)
+            scans_ns_all.append(np.asarray(sc_ns, dtype=np.int64))
             scans_t.append(sc_t)
             odoms.append(od)
             odoms_t.append(od_t)
@@ -62,12 +63,13 @@ class DROWDeviceDataset:
             for d_ns, wc, wa, wp in zip(seq["dets_ns"], seq["dets_wc"], seq["dets_wa"], seq["dets_wp"]):
                 hit = np.where(sc_ns == d_ns)[0]
                 if len(hit) > 0:
-                    self._samples.append((s_idx, int(hit[0]), wc, wa, wp))
+                    self._samples.append((s_idx, int(hit[0]), wc, wa, wp, int(d_ns)))
         if not self._samples:
             raise FileNotFoundError("No valid data")
         dev = self.device
         self.scans = torch.from_numpy(np.concatenate(scans)).to(dev)
         self.scans_t = torch.from_numpy(np.concatenate(scans_t)).to(dev)
+        self.scans_ns = torch.from_numpy(np.concatenate(scans_ns_all)).to(dev)
         self.odoms = torch.from_numpy(np.concatenate(odoms)).to(dev)
         self.odoms_t = torch.from_numpy(np.concatenate(odoms_t)).to(dev)
         # per-sample index tables and ALL annotations as one device CSR, built once: a batch is then
@@ -133,6 +135,14 @@ class DROWDeviceDataset:
         dets = self._gather_detections(idx)
         batch = self.pre(windows, odom0, odom1, dets)
         batch["odom0"] = odom0
+        # the remaining keys of the reference's sample dict (dataset_dr_spaam.py:346-381)
+        batch["odom1_t"] = self.odoms_t[odom_lo.long() + idx1.long()]
+        back = (torch.arange(self.num_scans + self.distance - 1, self.distance - 1, -1, device=dev)
+                * self.scan_stride)                                         # look-back of the template rows
+        rows = seq_first.long()[:, None] + (scan_idx.long()[:, None] - back[None, :]).clamp_(min=0)
+        batch["scans_ns"] = self.scans_ns[rows]
+        batch["seq_name"] = [self.seq_names[s[0]] for s in smp]
+        batch["dets_ns"] = [s[5] for s in smp]
         batch["dets_wc"] = [s[2] for s in smp]
         batch["dets_wa"] = [s[3] for s in smp]
         batch["dets_wp"] = [s[4] for s in smp]

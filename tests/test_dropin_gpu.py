@@ -198,6 +198,9 @@ def test_device_dataset_equals_reference_getitem(golden):
     batch = ds.get_batch(list(range(n)))
     assert torch.equal(batch["scans"].cpu(), torch.from_numpy(g["out_scans"]))            # window gather
     assert np.array_equal(batch["odom1"].cpu().numpy().astype(np.float32), g["out_odom1"])  # time association
+    assert np.array_equal(batch["odom1_t"].cpu().numpy(), g["out_odom1_t"])
+    assert np.array_equal(batch["scans_ns"].cpu().numpy(), g["out_scans_ns"].astype(np.int64))
+    assert np.array_equal(np.array(batch["dets_ns"]), g["out_dets_ns"].astype(np.int64))
     assert np.array_equal(batch["target_cls"].cpu().numpy(), g["out_target_cls"])
     np.testing.assert_allclose(batch["target_reg"].cpu().numpy(), g["out_target_reg"], atol=1e-6)
     np.testing.assert_allclose(batch["target_flow"].cpu().numpy(), g["out_target_flow"], atol=5e-6)

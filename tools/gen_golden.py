@@ -302,6 +302,9 @@ def main():
     for k in ("scans", "target_cls", "target_reg", "target_flow", "exclude_mask"):
         gd["out_" + k] = coll[k]
     gd["out_odom1"] = np.array(coll["odom1"])
+    gd["out_odom1_t"] = np.array(coll["odom1_t"])
+    gd["out_scans_ns"] = np.array(coll["scans_ns"])
+    gd["out_dets_ns"] = np.array(coll["dets_ns"])
     gd["out_input_first3"] = coll["input"][:3]
     np.savez_compressed(os.path.join(OUT, "dataset_items.npz"), **gd)
 
