@@ -293,3 +293,11 @@ def data_augmentation(sample_dict):
         target_reg[:, 0] = -target_reg[:, 0]
     sample_dict.update({"target_reg": target_reg, "scans": scans})
     return sample_dict
+
+
+def _phi_to_rotation_matrix(phi, is_3d=False):
+    """:601-606.  Rotation about z by `phi` as a float32 matrix (2x2, or 3x3 when is_3d)."""
+    c, s = np.cos(phi), np.sin(phi)
+    rot = np.eye(3 if is_3d else 2, dtype=np.float32)
+    rot[0, 0], rot[0, 1], rot[1, 0], rot[1, 1] = c, -s, s, c
+    return rot
