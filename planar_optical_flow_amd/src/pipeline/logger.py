@@ -85,6 +85,24 @@ class Logger:
         if self._tb is not None:
             self._tb.add_image(key, im, step)
 
+    def add_fig(self, key, fig, step, close_fig=False):
+        """A matplotlib figure as a [3, H, W] float image in the event log (reference logger.py:107-117)."""
+        if self._tb is not None:
+            fig.canvas.draw()
+            rgba = np.asarray(fig.canvas.buffer_rgba(), dtype=np.uint8)
+            self.add_im(key, rgba[..., :3].transpose(2, 0, 1).astype(np.float32) / 255.0, step)
+        if close_fig:
+            import matplotlib.pyplot as plt
+            plt.close(fig)
+
+    def save_fig(self, fig, fname, close_fig=False):
+        """The figure as a file under the run's image directory (reference :148-152)."""
+        if self._master:
+            fig.savefig(os.path.join(self._sub["image"], fname))
+        if close_fig:
+            import matplotlib.pyplot as plt
+            plt.close(fig)
+
     def flush(self):
         if self._tb is not None:
             self._tb.flush()

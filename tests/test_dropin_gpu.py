@@ -577,3 +577,29 @@ def test_box_regression_dataset_feeder(is_3d):
     assert {tuple(r) for r in xv[0, :, :D]} <= {tuple(r) for r in pts0}
     if len(pts0) <= 64:
         assert {tuple(r) for r in xv[0, :, :D]} == {tuple(r) for r in pts0}
+
+
+def test_get_dataloader_feeds_the_box_head_pipeline(tmp_path):
+    """get_dataloader -> device batches -> the reference-shaped Pipeline / Trainer with the box head: one
+    epoch of training and an evaluation run end to end on the device data path."""
+    from planar_optical_flow_amd.src.data_handle.get_dataloader import get_dataloader
+    from planar_optical_flow_amd.src.utils import eval_utils as eu
+    from src.model.get_model import get_model
+    frames = _box_frames(np.random.default_rng(11), n_frames=6, is_3d=True)
+    cfg = {"data_dir": "/data/JRDB", "frames": frames, "input_size": 64, "is_3d": True, "min_segment_size": 5,
+           "augmentation_kwargs": {"use_data_augmentation": True, "rot_max": 0.25, "dim_max": 0.1, "dist_max": 0.2,
+                                   "random_drop": 0.25}}
+    loader = get_dataloader("train", 8, 4, True, cfg)
+    assert len(loader) == -(-len(loader.dataset) // 8)
+    model = get_model({"type": "box_reg", "input_dim": 4, "target_dim": 5, "dropout": 0.3}).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), 1e-3)
+    seen = 0
+    for batch in loader:
+        assert batch["input"].is_cuda and batch["input"].shape[1:] == (64, 4)
+        loss = eu.model_fn_Bb_regression(model, batch)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        assert torch.isfinite(loss)
+        seen += batch["input"].shape[0]
+    assert seen == len(loader.dataset)
