@@ -349,8 +349,13 @@ def bench_cutout(ops, synth, tab, dev):
     ms = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out, **kw), 10)
     per_sample = T * N * 4 + N * T * P * 4  # 513 000 B
     ach = per_sample * B / (ms * 1e-3) / 1e9
+    # the two opt-in forms (same indices): float32 value arithmetic; float16 output storage (config 5)
+    ms_f32 = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out, exact_values=False, **kw), 10)
+    out16 = torch.empty((B, N, T, P), dtype=torch.float16, device=dev)
+    ms_f16 = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out16, out_dtype=torch.float16, **kw), 10)
     return {"workload": "cutout T=5 N=450 P=56 area_mode, batch %d" % B, "ms_per_call": ms,
             "samples_per_s": B / (ms * 1e-3),
+            "variants_ms": {"float32_value_path": ms_f32, "float16_output": ms_f16},
             "roofline": {"bound": "hbm", "kernel": "cutout_area_kernel + cutout_kernel", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
 
