@@ -29,7 +29,8 @@ _CUTOUT_TYPES = ("cutout", "cutout_gating", "cutout_spatial")
 class DROWDataset2(DROWDeviceDataset):
     def __init__(self, data_path, split="train", num_scans=5, network_type="cutout", train_with_val=False,
                  cutout_kwargs=None, polar_grid_kwargs=None, use_data_augumentation=False, pedestrian_only=False,
-                 scan_stride=1, pt_stride=1, max_scan_dist=6, device="cuda", seed=0, sequences=None):
+                 scan_stride=1, pt_stride=1, max_scan_dist=6, device="cuda", seed=0, sequences=None,
+                 drop_static=True):
         if pt_stride != 1:
             raise NotImplementedError("pt_stride != 1 (marked for removal in the reference) is not supported")
         if network_type == "fc2d_fea":
@@ -43,7 +44,7 @@ class DROWDataset2(DROWDeviceDataset):
         seqs = sequences if sequences is not None else drow_io.load_sequences(data_path, split)
         # the store computes targets only; the network input is built here after the augmentation
         super().__init__(seqs, num_scans=num_scans, cutout_kwargs=None, pedestrian_only=pedestrian_only,
-                         scan_stride=scan_stride, device=device)
+                         scan_stride=scan_stride, device=device, drop_static=drop_static)
 
     def get_batch(self, indices):
         batch = super().get_batch(indices)

@@ -642,3 +642,42 @@ def test_drow_dataset2_and_loaders_from_files(golden, tmp_path):
     assert eval_loader is None and sum(x["input"].shape[0] for x in train_loader) == n
     one = ds[0]
     assert one["input"].shape == (450, 6, 56) and one["scans"].shape == (6, 450)
+
+
+def test_train_utils_trainer_on_device_loader(golden, tmp_path):
+    """The DR-SPAAM training script's pieces (train_utils.Trainer + LucasScheduler + checkpoints) driven by
+    the device loader and model_fn_dr_spaam: two epochs, a checkpoint that loads back, evaluation metrics."""
+    from dataset_fixture import CUTOUT_KW, load_sequences
+    from planar_optical_flow_amd.src.utils.dataset_dr_spaam import DROWDataset2
+    from planar_optical_flow_amd.src.data_handle.get_dataloader import DeviceBatchLoader
+    from planar_optical_flow_amd.src.utils import eval_utils as eu, train_utils as tu
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW, flow_loss
+
+    class FlowHead(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.net = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+            self.head = torch.nn.Linear(12, 2)
+            self.loss_fn = flow_loss
+
+        def forward(self, x, cur_scan):
+            pc, pr, ff = self.net(x)
+            return pc, pr, self.head(torch.cat((ff, cur_scan.unsqueeze(-1)), dim=-1))
+
+    g = golden("dataset_items")
+    ds = DROWDataset2(None, num_scans=5, network_type="cutout", cutout_kwargs=CUTOUT_KW, sequences=load_sequences(g),
+                      drop_static=False)
+    loader = DeviceBatchLoader(ds, 4, shuffle=True)
+    torch.manual_seed(1)
+    model = FlowHead().cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=tu.lr_scheduler())
+    sched = tu.LucasScheduler(opt, 0, 1e-3, 2, 1e-5)
+    tb = tu.create_tb_logger(str(tmp_path))
+    tr = tu.Trainer(model, eu.model_fn_dr_spaam, opt, str(tmp_path), sched, model_fn_eval=eu.model_fn_eval,
+                    grad_norm_clip=1.0, tb_logger=tb)
+    tr.train(num_epochs=2, train_loader=loader, eval_loader=[ds.get_batch([0, 1, 2])], ckpt_save_interval=1)
+    assert abs(sched.get_lr() - 1e-3 * (1e-5 / 1e-3) ** ((1 + (len(loader) - 1) / len(loader)) / 2)) < 1e-12
+    it, ep = tu.load_checkpoint(FlowHead().cuda(), None, filename=str(tmp_path / "ckpt_e2.pth"))
+    assert ep == 2 and it == 2 * len(loader)
+    with pytest.raises(FileNotFoundError):
+        tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
