@@ -677,6 +677,12 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
                     grad_norm_clip=1.0, tb_logger=tb)
     tr.train(num_epochs=2, train_loader=loader, eval_loader=[ds.get_batch([0, 1, 2])], ckpt_save_interval=1)
     assert abs(sched.get_lr() - 1e-3 * (1e-5 / 1e-3) ** ((1 + (len(loader) - 1) / len(loader)) / 2)) < 1e-12
+    res = eu.eval_dr_spaam(model, [ds.get_batch([0, 1, 2]), ds.get_batch([3, 4, 5])], output_dir=str(tmp_path / "ev"))
+    assert res["epe"].shape == (6,) and res["pred_flow"].shape == (6, 450, 2) and np.isfinite(res["eval_loss"])
+    b0 = ds.get_batch([0, 1, 2])
+    want = R.flow_to_global(b0["target_flow"][0].cpu().numpy().astype(np.float64), R.laser_phi())
+    np.testing.assert_allclose(res["target_flow"][0], want, atol=1e-5)
+    assert (tmp_path / "ev" / "flow_eval.npz").exists()
     it, ep = tu.load_checkpoint(FlowHead().cuda(), None, filename=str(tmp_path / "ckpt_e2.pth"))
     assert ep == 2 and it == 2 * len(loader)
     with pytest.raises(FileNotFoundError):
