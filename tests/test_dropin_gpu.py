@@ -687,3 +687,22 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
     assert ep == 2 and it == 2 * len(loader)
     with pytest.raises(FileNotFoundError):
         tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
+
+
+def test_bench_two_ranks_share_the_gpu():
+    """The driver's N > 1 launch line, rehearsed with two ranks on the one GPU (gloo instead of RCCL, which
+    needs a device per rank): barriers, max-over-ranks timing and the single JSON line of rank 0."""
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, POF_BENCH_SHARE_GPU="1", POF_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29517", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "40",
+           "--warmup", "8"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=repo, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["global_batch"] == 2 * 4096 and d["epe_vs_oracle_m"] < 1e-5
+    assert "cpu_baseline" not in d and "cutout" not in d       # N = 1 only
