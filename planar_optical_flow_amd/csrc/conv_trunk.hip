@@ -10,11 +10,11 @@
 //   * B operand (activations): lane (n, h) needs x[seq(n)][ci + h][l(n) + tap - 1]: for a fixed
 //     (tap, ci) the 32 columns are consecutive floats, so the operand is a coalesced global load
 //     (zero at the sequence borders); the three taps re-read the same lines from L1.
-//   * A operand (weights): pre-transposed on the host to [tap][ci][co]; a K-chunk (16 input
+//   * A operand (weights): pre-transposed on the host to [tap][ci][co]; a K-chunk (4 input
 //     channels x 3 taps) x (128 output channels) is staged in LDS per workgroup and every lane
 //     reads consecutive co.
 //   * one wave = 32 columns x up to 128 output channels (4 accumulator tiles): one activation
-//     load feeds 4 MFMAs; loads are issued a block of 8 k-steps ahead.
+//     load feeds 4 MFMAs; the next chunk's loads are in flight during the MFMAs; 116 VGPRs -> 4 waves per SIMD.
 //   * epilogue: y = acc * scale[co] + shift[co] (BatchNorm folded with the conv bias), LeakyReLU,
 //     optional max over position pairs (adjacent lanes), store.
 #include <algorithm>
@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int kCvWaves = 4;
-constexpr int kCvCC = 16;            // input channels per LDS weight chunk
+constexpr int kCvCC = 4;             // input channels per LDS weight chunk
 constexpr int kCvRows = 3 * kCvCC;   // K rows per chunk (tap-major)
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
@@ -40,7 +40,7 @@ struct ConvArgs {
 };
 
 template <int CT>
-__global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_kernel(ConvArgs a)
+__global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
 {
     constexpr int COG = 32 * CT;                       // output channels per workgroup
     constexpr int NT = 64 * kCvWaves;

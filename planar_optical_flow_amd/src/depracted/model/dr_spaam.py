@@ -145,7 +145,7 @@ class DROW(nn.Module):
 
     def _run_block(self, x, name, pool):
         """One trunk block; pooled blocks pool after their last layer.  Three routes:
-        eval + fuse_for_inference(): the HIP conv kernels (19 ms per B = 32 forward); eval without it on
+        eval + fuse_for_inference(): the HIP conv kernels (17 ms per B = 32 forward); eval without it on
         the GPU: the channels-last GEMM form below (39 ms; MIOpen's inference path takes 234 ms on these
         shapes); training and CPU: the plain torch modules (MIOpen's training-mode solvers are fine:
         40 ms per fwd + bwd at B = 8 against 58 ms for the GEMM form)."""
