@@ -296,10 +296,6 @@ __global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const flo
     const int r = lane & 31, h = lane >> 5;
     const int nchunk = (C + 31) >> 5, nblk = (n + 31) >> 5;
     const int units = nchunk * nblk * 2;
-    auto band = [&](int a, int bb) -> float {   // G[a][bb], zero outside the band / the scan
-        const int s = bb - a + HB;
-        return (a >= 0 && a < n && bb >= 0 && bb < n && s >= 0 && s < W) ? s_g[a * W + s] : 0.0f;
-    };
     for (int u = wave; u < units; u += kBwdWaves) {
         const int which = u & 1;                 // 0: d_f1 (reads f2), 1: d_f2 (reads f1)
         const int blk = (u >> 1) % nblk, chunk = (u >> 1) / nblk;
@@ -307,7 +303,6 @@ __global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const flo
         const float *src = (which == 0 ? f2 : f1) + (long long)b * C * n;
         float *dst = (which == 0 ? d_f1 : d_f2) + (long long)b * C * n;
         const int crow = min(c0 + r, C - 1);     // clamped row keeps masked lanes' loads in bounds
-        const bool cvalid = c0 + r < C;
         const float *row = src + (long long)crow * n;
         const int w0 = max(p0 - HB, 0), w1 = min(p0 + 31 + HB, n - 1);
         f32x16 acc = {0};
@@ -327,16 +322,34 @@ __global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const flo
                 }
             }
         }
+        // B operands of the whole tile from the band image first (one LDS round trip), then the MFMAs.
+        // G[a][bb] lives at s_g[a * W + bb - a + HB]: with the lane's fixed index `fx` (row a for d_f1,
+        // column bb for d_f2) the address is linear in the contraction position `pos`
+        //   d_f1: fx * (W - 1) + HB + pos            d_f2: pos * (W - 1) + HB + fx
+        // and the entry exists iff |pos - fx| <= HB, pos < n and fx < n: one range test per element.
+        float bvv[kMaxQ][4];
+        const int fx = p0 + r;
+        const int pos_lo = max(fx - HB, 0), pos_span = (fx < n ? min(fx + HB, n - 1) : -1) - pos_lo;   // < 0: no entry
+        const int stride = which == 0 ? 1 : (W - 1);
+        const int addr0 = (which == 0 ? fx * (W - 1) + HB : HB + fx) + (w0 + 4 * h) * stride;
+#pragma unroll
+        for (int qi = 0; qi < kMaxQ; ++qi) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = 8 * qi + t;                       // compile-time offset from this lane's first position
+                const int pos = w0 + 4 * h + k;
+                const bool ok = (unsigned)(pos - pos_lo) <= (unsigned)pos_span && pos_span >= 0;
+                bvv[qi][t] = ok ? s_g[addr0 + k * stride] : 0.0f;
+            }
+        }
 #pragma unroll
         for (int qi = 0; qi < kMaxQ; ++qi) {
             const int q = w0 + 8 * qi;
             if (q > w1) break;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int pos = q + 4 * h + t;
-                const float av = (cvalid && pos < n) ? x[qi][t] : 0.0f;
-                const float bv = which == 0 ? band(p0 + r, pos) : band(pos, p0 + r);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+                // positions past the row end carry a zero B operand; rows c >= C are never stored
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x[qi][t], bvv[qi][t], acc, 0, 0, 0);
             }
         }
         // C/D layout: col = lane & 31 (position), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (channel)
