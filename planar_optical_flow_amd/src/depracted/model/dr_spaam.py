@@ -143,6 +143,13 @@ class DROW(nn.Module):
         self._fused = fused
         return self
 
+    def train(self, mode=True):
+        """Entering training mode drops the folded inference parameters: the weights and the BatchNorm
+        running statistics are about to change, so ``fuse_for_inference()`` has to be called again."""
+        if mode:
+            self._fused = None
+        return super().train(mode)
+
     def _run_block(self, x, name, pool):
         """One trunk block; pooled blocks pool after their last layer.  Three routes:
         eval + fuse_for_inference(): the HIP conv kernels (17 ms per B = 32 forward); eval without it on

@@ -425,6 +425,11 @@ def test_spatial_drow_forward_equals_reference(golden):
         np.testing.assert_allclose(pr2.cpu().numpy(), g["eval_reg"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(ff2.cpu().numpy(), g["eval_feat"], rtol=1e-3, atol=2e-3)
         np.testing.assert_allclose(pc2.cpu().numpy(), pc.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        # streaming inference on the fused trunk
+        _, _, tmpl0, _ = m(x[:, :, 3:4], testing=True)
+        c1, r1, _, f1 = m(x[:, :, 4:5], testing=True, fea_template=tmpl0)
+        np.testing.assert_allclose(c1.cpu().numpy(), g["stream_cls"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(f1.cpu().numpy(), g["stream_feat"], rtol=1e-3, atol=2e-3)
     m.train()
     pc, pr, ff = m(x)
     np.testing.assert_allclose(pc.detach().cpu().numpy(), g["train_cls"], rtol=2e-3, atol=1e-3)
@@ -437,6 +442,12 @@ def test_spatial_drow_forward_equals_reference(golden):
         dc, dr_ = d(torch.from_numpy(g["drow_x"]).cuda())
     np.testing.assert_allclose(dc.cpu().numpy(), g["drow_cls"], rtol=1e-3, atol=2e-4)
     np.testing.assert_allclose(dr_.cpu().numpy(), g["drow_reg"], rtol=1e-3, atol=2e-4)
+    d.fuse_for_inference()
+    with torch.no_grad():
+        dc2, dr2 = d(torch.from_numpy(g["drow_x"]).cuda())
+    np.testing.assert_allclose(dc2.cpu().numpy(), g["drow_cls"], rtol=1e-3, atol=2e-4)
+    np.testing.assert_allclose(dr2.cpu().numpy(), g["drow_reg"], rtol=1e-3, atol=2e-4)
+    assert m._fused is None                         # m.train() above dropped the folded parameters
 
 
 def test_prototype_forward_equals_reference(golden):
