@@ -717,3 +717,22 @@ def test_bench_two_ranks_share_the_gpu():
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 2 * 4096 and d["epe_vs_oracle_m"] < 1e-5
     assert "cpu_baseline" not in d and "cutout" not in d       # N = 1 only
+
+
+def test_box_head_gpu_forward_equals_reference(golden):
+    """The box head on the device (1x1 convolutions issued as GEMMs in eval mode) against the reference's CPU
+    forward with identical seeded weights, 2-D and 3-D variants; train mode uses the modules and agrees."""
+    from src.model.get_model import get_model
+    g = golden("box_head")
+    for tag, cfg_m in (("2d", {"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}),
+                       ("3d", {"type": "box_reg", "input_dim": 4, "target_dim": 5, "dropout": 0.3})):
+        torch.manual_seed(61)
+        m = get_model(cfg_m).cuda().eval()
+        x = torch.from_numpy(g["in_" + tag]).cuda()
+        with torch.no_grad():
+            y = m(x)
+            m.backbone.gemm_pointwise = False
+            y_mod = m(x)
+            m.backbone.gemm_pointwise = True
+        np.testing.assert_allclose(y.cpu().numpy(), g["out_" + tag], rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(y.cpu().numpy(), y_mod.cpu().numpy(), rtol=1e-4, atol=1e-5)
