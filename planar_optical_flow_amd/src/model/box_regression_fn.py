@@ -19,6 +19,11 @@ def _to_model(x, model):
     return x.to(dev, non_blocking=True).float()
 
 
+def _np(x):
+    """Host copy of a batch entry (NumPy array, list, or a device tensor of the device data sets)."""
+    return x.detach().cpu().numpy() if torch.is_tensor(x) else np.asarray(x)
+
+
 def _model_fn(model, batch):
     """-> (loss tensor, tb_dict, rtn_dict{"pred"})."""
     tb_dict, rtn_dict = {}, {}
@@ -30,10 +35,10 @@ def _model_fn(model, batch):
 
 def _model_eval_fn(model, batch):
     loss, tb_dict, rtn = _model_fn(model, batch)
-    target = np.array(batch["target"], dtype=np.float64, copy=True)
+    target = np.array(_np(batch["target"]), dtype=np.float64, copy=True)
     pred = rtn["pred"].detach().cpu().numpy().astype(np.float64)
-    det_center, box_center = np.asarray(batch["det_center"]), np.asarray(batch["box_center"])
-    inp = np.asarray(batch["input"])
+    det_center, box_center = _np(batch["det_center"]), _np(batch["box_center"])
+    inp = _np(batch["input"])
     is_3d = box_center.shape[1] == 3
     loss_z = np.zeros(len(pred))
     if is_3d:
@@ -47,7 +52,7 @@ def _model_eval_fn(model, batch):
         centre = det_center
     pred[:, -1] += inp[:, 0, -1]                 # orientation = input angle + regressed residual
     pred = np.hstack((centre, pred))
-    target[:, -1] = np.asarray(batch["rot_z"])
+    target[:, -1] = _np(batch["rot_z"])
     target = np.hstack((box_center[:, :2], target))
     dev_index = next(model.parameters()).device.index or 0
     per_sample = rotate_iou_batched(pred, batch["target_neighbor"], device_id=dev_index, is_3d=is_3d)

@@ -52,7 +52,9 @@ def model_fn_dr_spaam(model, batch):
 
 
 def model_fn_Bb_regression(model, batch):
-    """Box head step: the loss is on the box parameters after the centre, target[:, 2:]."""
+    """Box head step of the legacy scripts: the loss is on target[:, 2:] (written for a data set whose target
+    still carried the box centre; the current JRDBBoxRegressionDataset already strips it -- use
+    ``BoundingBoxRegressor.model_fn`` with it, as the pipeline's Trainer does)."""
     pred = model(_as_dev_f32(batch["input"]))
     return model.loss_fn(pred, _as_dev_f32(batch["target"])[:, 2:])
 

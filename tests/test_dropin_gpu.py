@@ -607,13 +607,17 @@ def test_get_dataloader_feeds_the_box_head_pipeline(tmp_path):
     seen = 0
     for batch in loader:
         assert batch["input"].is_cuda and batch["input"].shape[1:] == (64, 4)
-        loss = eu.model_fn_Bb_regression(model, batch)
+        loss = model.model_fn(model, batch)[0]
         opt.zero_grad()
         loss.backward()
         opt.step()
         assert torch.isfinite(loss)
         seen += batch["input"].shape[0]
     assert seen == len(loader.dataset)
+    model.eval()
+    with torch.no_grad():
+        _, _, ev = model.model_eval_fn(model, next(iter(loader)))       # batched rotated IoU on device batches
+    assert 0.0 <= ev["iou"] <= 1.0 and np.isfinite(ev["loss_dim"])
 
 
 def test_drow_dataset2_and_loaders_from_files(golden, tmp_path):
@@ -736,3 +740,29 @@ def test_box_head_gpu_forward_equals_reference(golden):
             m.backbone.gemm_pointwise = True
         np.testing.assert_allclose(y.cpu().numpy(), g["out_" + tag], rtol=1e-4, atol=1e-4)
         np.testing.assert_allclose(y.cpu().numpy(), y_mod.cpu().numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_box_head_overfits_one_sample():
+    """The reference's _DEBUG_ONE_SAMPLE check (jrdb_dataset.py:13, :100-101): fed the same sample again and
+    again the network 'should fit perfectly' -- through the device feeder, the adapter and Adam."""
+    from planar_optical_flow_amd.src.data_handle.jrdb_dataset import JRDBBoxRegressionDataset
+    from planar_optical_flow_amd.src.utils import eval_utils as eu
+    from src.model.get_model import get_model
+    cfg = {"input_size": 64, "is_3d": False, "min_segment_size": 5,
+           "augmentation_kwargs": {"use_data_augmentation": False, "rot_max": 0.0, "dim_max": 0.0, "dist_max": 0.0,
+                                   "random_drop": 0.0}}
+    ds = JRDBBoxRegressionDataset("val", cfg, _box_frames(np.random.default_rng(3), n_frames=2, is_3d=False),
+                                  rng=np.random.default_rng(0))
+    torch.manual_seed(0)
+    model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda().train()
+    opt = torch.optim.Adam(model.parameters(), 2e-3)
+    batch = ds.get_batch([0, 1, 2, 3])          # rot_max = 0: the same inputs and targets every time
+    first = last = None
+    for it in range(150):
+        loss = model.model_fn(model, batch)[0]
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        first = loss.item() if first is None else first
+        last = loss.item()
+    assert last < 0.1 * first and last < 0.15, (first, last)
