@@ -28,6 +28,8 @@ class DROWBatchPreprocessor:
         self.device = torch.device(device)
         self.canonical_flow = canonical_flow
         self.tab = ops.phi_table(angle_inc, num_pts, self.device)
+        self._ws = [None, None]      # two per-sample parameter workspaces (look-ahead mode)
+        self._cur, self._primed = 0, None
 
     def make_detections(self, dets_wc, dets_wa, dets_wp):
         """Ragged python/NumPy detection lists (one entry per sample, each a list
@@ -46,14 +48,45 @@ class DROWBatchPreprocessor:
         cls = np.concatenate(cls) if cls else np.zeros(0, dtype=np.uint8)
         return ops.DetCSR.from_numpy(np.asarray(offs, dtype=np.int32), rphi, cls, self.device)
 
-    def __call__(self, scans, odom0, odom1, dets):
+    def _workspace(self, slot, B, D):
+        need = ops.scan_preprocess_workspace_bytes(B, D)
+        ws = self._ws[slot]
+        if ws is None or ws.numel() < need:
+            ws = self._ws[slot] = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return ws
+
+    @staticmethod
+    def _key(odom0, odom1, dets):
+        return (odom0.data_ptr(), odom1.data_ptr(), dets.rphi.data_ptr(), dets.offsets.data_ptr(), odom0.shape[0])
+
+    def __call__(self, scans, odom0, odom1, dets, lookahead=None):
         """scans [B,T+1,N] float32 (template rows then the current scan, as
         ``np.vstack((scans, cur_scan))`` in the reference), odom0/odom1 [B,3]
-        float64, dets: DetCSR.  Returns the collated batch dict."""
+        float64, dets: DetCSR.  Returns the collated batch dict.
+
+        lookahead = (odom0, odom1, dets) of the NEXT batch enables the chained launch: the per-sample
+        parameters of the next batch (rigid motions, detection centres) are evaluated on spare workgroups
+        of THIS batch's streaming launch, and the next call -- given those same tensors -- is a single
+        launch (15 us instead of 20 us per 4096 scans).  Without it every call is self-contained."""
         labels = (1, 1, 1) if self.pedestrian_only else (1, 2, 3)
-        out = ops.scan_preprocess(scans, self.tab, odom0, odom1, dets, flow_kind=ops.FLOW_DISPLACEMENT,
-                                  canonical=self.canonical_flow, labels=labels,
-                                  want=("flow", "target_cls", "target_reg", "exclude_mask"))
+        kw = dict(flow_kind=ops.FLOW_DISPLACEMENT, canonical=self.canonical_flow, labels=labels,
+                  want=("flow", "target_cls", "target_reg", "exclude_mask"))
+        if lookahead is None and self._primed is None:
+            out = ops.scan_preprocess(scans, self.tab, odom0, odom1, dets, **kw)
+        else:
+            B, D = odom0.shape[0], int(dets.rphi.shape[0])
+            ws = self._workspace(self._cur, B, D)
+            if self._primed != self._key(odom0, odom1, dets):       # not announced by the previous call
+                ops.scan_preprocess(scans, self.tab, odom0, odom1, dets, workspace=ws, phases=1, **kw)
+            nb = None
+            if lookahead is not None:
+                n0, n1, nd = lookahead
+                nb = {"odom0": n0, "odom1": n1, "dets": nd,
+                      "workspace": self._workspace(1 - self._cur, n0.shape[0], int(nd.rphi.shape[0]))}
+            out = ops.scan_preprocess(scans, self.tab, odom0, odom1, dets, workspace=ws, phases=2, next_batch=nb,
+                                      **kw)
+            self._primed = self._key(*lookahead) if lookahead is not None else None
+            self._cur = 1 - self._cur
         batch = {
             "scans": scans,
             "target_cls": out["target_cls"],

@@ -766,3 +766,27 @@ def test_box_head_overfits_one_sample():
         first = loss.item() if first is None else first
         last = loss.item()
     assert last < 0.1 * first and last < 0.15, (first, last)
+
+
+def test_batch_preprocessor_lookahead_chain():
+    """DROWBatchPreprocessor with look-ahead: the chained single-launch sequence A -> B -> C gives the same
+    batches as three self-contained calls, also when an unannounced batch interrupts the chain."""
+    from planar_optical_flow_amd.preprocess import DROWBatchPreprocessor
+    pre = DROWBatchPreprocessor(cutout_kwargs=None)
+    plain = DROWBatchPreprocessor(cutout_kwargs=None)
+    data = []
+    for seed in (91, 92, 93, 94):
+        sb = synth.make_batch(seed=seed, B=300, T=3, mixed_classes=True)
+        o, r, c = sb.det_csr()
+        from planar_optical_flow_amd import ops as _ops
+        dev_t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        data.append((dev_t(sb.scans), dev_t(sb.odom0), dev_t(sb.odom1), _ops.DetCSR.from_numpy(o, r, c, "cuda")))
+    ref = [plain(*d) for d in data]
+    keys = ("target_cls", "target_reg", "target_flow", "exclude_mask")
+    got_a = pre(*data[0], lookahead=data[1][1:])
+    got_b = pre(*data[1], lookahead=data[2][1:])
+    got_d = pre(*data[3])                         # not the announced batch: parameters are recomputed
+    got_c = pre(*data[2], lookahead=None)
+    for got, want in ((got_a, ref[0]), (got_b, ref[1]), (got_d, ref[3]), (got_c, ref[2])):
+        for k in keys:
+            assert torch.equal(got[k], want[k]), k
