@@ -198,7 +198,8 @@ int pof_cutout_ex(const float *scans, int B, int T, int N, const double *tab, in
                   double padding_val, int area_mode, int value_mode, float *out, int32_t *workspace,
                   int32_t *dbg_lo, pof_stream_t stream);
 
-/* BASELINE config 5 storage: the same cutout written as IEEE float16 (the float32 result
+/* BASELINE config 5 storage (reference src/utils/utils.py:259-334 returns float32): the same cutout
+ * written as IEEE float16 (the float32 result
  * rounded to nearest even once more), out_f16 [B][ceil(N/stride)][T][P] half.  Halves the
  * dominant write traffic (3600*11*(4 + 56*2) bytes per dense sample). */
 int pof_cutout_f16(const float *scans, int B, int T, int N, const double *tab, int stride, int centered,
@@ -238,12 +239,14 @@ int pof_flow_errors(const float *pred, const float *target, const float *mask, i
 int pof_band_correlation(const float *feat1, const float *feat2, float *out, int B, int C, int n,
                          int kernel_size, int max_disp, pof_stream_t stream);
 
-/* BASELINE config 5 ("fp16 correlation"): the same with float16 feature storage.  Products and
+/* BASELINE config 5 ("fp16 correlation"; no counterpart in the reference, which is float32
+ * throughout prototype.py:118-156): the same with float16 feature storage.  Products and
  * accumulation are float32 (a float16 converts exactly), the output stays float32. */
 int pof_band_correlation_f16(const void *feat1_f16, const void *feat2_f16, float *out, int B, int C, int n,
                              int kernel_size, int max_disp, pof_stream_t stream);
 
-/* Backward of pof_band_correlation (training Prototype end to end): given
+/* Backward of pof_band_correlation (training Prototype end to end; in the reference this is torch
+ * autograd through the unfold / matmul / gather of src/depracted/model/prototype.py:118-156): given
  * g_out = dL/d out [B][D][n] returns dL/d feat1, dL/d feat2 [B][C][n].  n <= 512. */
 int pof_band_correlation_backward(const float *feat1, const float *feat2, const float *g_out,
                                   float *d_feat1, float *d_feat2, int B, int C, int n,
@@ -261,13 +264,15 @@ int pof_spatial_attention(const float *emb_x, const float *emb_t, const float *x
                           int B, int N, int E, int F, int window, double alpha, float *band,
                           float *prob, float *out, pof_stream_t stream);
 
-/* Same with the large tensors (x, tmpl, out: [B][N][F]) stored as float16 and float32 arithmetic;
+/* BASELINE config 5 storage (the reference's dr_spaam.py:163-217 is float32 throughout): the same
+ * with the large tensors (x, tmpl, out: [B][N][F]) stored as float16 and float32 arithmetic;
  * the embeddings, band and prob stay float32.  Halves the traffic of the merge kernel. */
 int pof_spatial_attention_f16(const float *emb_x, const float *emb_t, const void *x_f16, const void *tmpl_f16,
                               int B, int N, int E, int F, int window, double alpha, float *band, float *prob,
                               void *out_f16, pof_stream_t stream);
 
-/* Backward of pof_spatial_attention (training SpatialDROW through the gate).
+/* Backward of pof_spatial_attention (training SpatialDROW through the gate; in the reference torch
+ * autograd through src/depracted/model/dr_spaam.py:183-215).
  * g_out = dL/d out [B][N][F]; g_band = dL/d band [B][N][w] or NULL.
  * dsim [B][N][w] is scratch.  Outputs: d_emb_x, d_emb_t [B][N][E]; d_x, d_tmpl [B][N][F]. */
 int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const float *tmpl,
@@ -312,7 +317,8 @@ int pof_gather_windows(const float *scans_all, const int32_t *seq_first, const i
                        int B, int num_scans, int distance, int stride, int N, float *out,
                        int32_t *row_cur, int32_t *row_prev, pof_stream_t stream);
 
-/* odom{0,1}[b] = odoms[argmin_k |odoms_t[k] - scans_t[row_{prev,cur}[b]]|], k in
+/* Scan <-> odometry time association of __getitem__ (src/utils/dataset_dr_spaam.py:369-378):
+ * odom{0,1}[b] = odoms[argmin_k |odoms_t[k] - scans_t[row_{prev,cur}[b]]|], k in
  * [odom_lo[b], odom_hi[b]) (the sample's sequence), float32 differences, first
  * minimum wins (np.argmin).  odoms [O_total][3] float32 -> odom0/odom1 [B][3] float64;
  * idx0/idx1 (optional) receive the indices relative to odom_lo. */
