@@ -158,10 +158,24 @@ class DROW(nn.Module):
         40 ms per fwd + bwd at B = 8 against 58 ms for the GEMM form)."""
         fused = getattr(self, "_fused", None)
         if fused is not None and not self.training and x.is_cuda and not torch.is_grad_enabled():
-            out = x.contiguous().float()
+            x = x.contiguous().float()
             layers = fused[name]
-            for i, (wt, scale, shift) in enumerate(layers):
-                out = ops.conv3_bn_lrelu(out, wt, scale, shift, pool=pool and i == len(layers) - 1)
+
+            def run(seqs):
+                for i, (wt, scale, shift) in enumerate(layers):
+                    seqs = ops.conv3_bn_lrelu(seqs, wt, scale, shift, pool=pool and i == len(layers) - 1)
+                return seqs
+            # large batches go through the block in slabs of sequences: the intermediate activations
+            # (64 x 56 floats per sequence and layer) stay bounded, only the block output is full size
+            slab = getattr(self, "fused_slab", 1 << 18)
+            S = x.shape[0]
+            if S <= slab:
+                return run(x)
+            first = run(x[:slab])
+            out = torch.empty((S,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+            out[:slab] = first
+            for s0 in range(slab, S, slab):
+                out[s0:s0 + slab] = run(x[s0:s0 + slab])
             return out
         if x.is_cuda and not self.training and getattr(self, "gemm_trunk", True):
             return self._run_block_gemm(x, getattr(self, name), pool)

@@ -425,6 +425,10 @@ def test_spatial_drow_forward_equals_reference(golden):
         np.testing.assert_allclose(pr2.cpu().numpy(), g["eval_reg"], rtol=1e-3, atol=2e-4)
         np.testing.assert_allclose(ff2.cpu().numpy(), g["eval_feat"], rtol=1e-3, atol=2e-3)
         np.testing.assert_allclose(pc2.cpu().numpy(), pc.cpu().numpy(), rtol=1e-4, atol=1e-5)
+        m.fused_slab = 7                                   # slabs of sequences (large-batch memory bound)
+        pc3, pr3, ff3 = m(x)
+        assert torch.equal(pc3, pc2) and torch.equal(pr3, pr2) and torch.equal(ff3, ff2)
+        del m.fused_slab
         # streaming inference on the fused trunk
         _, _, tmpl0, _ = m(x[:, :, 3:4], testing=True)
         c1, r1, _, f1 = m(x[:, :, 4:5], testing=True, fea_template=tmpl0)
