@@ -33,10 +33,12 @@ class DROWBatchPreprocessor:
 
     def make_detections(self, dets_wc, dets_wa, dets_wp):
         """Ragged python/NumPy detection lists (one entry per sample, each a list
-        of (r, phi)) -> device CSR in the reference's wc + wa + wp order."""
+        of (r, phi)) -> device CSR in the reference's wc + wa + wp order.  All three classes are kept
+        also for pedestrian_only: the dynamic mask of the reference always uses all of them
+        (dataset_dr_spaam.py:405), only the regression target ignores wheelchairs and walkers."""
         offs, rphi, cls = [0], [], []
         for wc, wa, wp in zip(dets_wc, dets_wa, dets_wp):
-            groups = [(2, wp)] if self.pedestrian_only else [(0, wc), (1, wa), (2, wp)]
+            groups = [(0, wc), (1, wa), (2, wp)]
             n = 0
             for c, d in groups:
                 d = np.asarray(d, dtype=np.float64).reshape(-1, 2)
@@ -68,8 +70,11 @@ class DROWBatchPreprocessor:
         parameters of the next batch (rigid motions, detection centres) are evaluated on spare workgroups
         of THIS batch's streaming launch, and the next call -- given those same tensors -- is a single
         launch (15 us instead of 20 us per 4096 scans).  Without it every call is self-contained."""
-        labels = (1, 1, 1) if self.pedestrian_only else (1, 2, 3)
-        kw = dict(flow_kind=ops.FLOW_DISPLACEMENT, canonical=self.canonical_flow, labels=labels,
+        # pedestrian_only (utils.py:165-168): only persons can be associated (label 1); a zero association
+        # radius keeps the other classes out of the target while they still carve the dynamic mask
+        labels = (0, 0, 1) if self.pedestrian_only else (1, 2, 3)
+        radii = (0.0, 0.0, 0.35) if self.pedestrian_only else (0.6, 0.4, 0.35)
+        kw = dict(flow_kind=ops.FLOW_DISPLACEMENT, canonical=self.canonical_flow, labels=labels, assoc_radius=radii,
                   want=("flow", "target_cls", "target_reg", "exclude_mask"))
         if lookahead is None and self._primed is None:
             out = ops.scan_preprocess(scans, self.tab, odom0, odom1, dets, **kw)

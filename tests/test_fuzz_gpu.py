@@ -1,0 +1,129 @@
+"""Seeded random-shape sweeps of the HIP entry points against the oracle: geometries, strides, window
+parameters, batch sizes and detection counts that the hand-picked cases do not cover.  Every case is
+small (the oracle is per-sample NumPy); the bar is the same as in test_hip_parity.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_numpy as R  # noqa: E402
+from planar_optical_flow_amd import synth  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from planar_optical_flow_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_cutout_bit_exact(ops, seed):
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([33, 64, 90, 180, 255, 450, 720]))
+    T = int(rng.integers(1, 7))
+    P = int(rng.choice([8, 12, 17, 32, 48, 56, 60]))
+    inc = float(rng.choice([0.25, 0.5, 1.0, 2.0]))
+    kw = dict(stride=int(rng.choice([1, 1, 2, 3])), centered=bool(rng.integers(0, 2)), fixed=bool(rng.integers(0, 2)),
+              window_width=float(rng.choice([0.5, 1.0, 1.66, 3.0])), window_depth=float(rng.choice([0.3, 0.5, 1.0, 0.7])),
+              num_cutout_pts=P, padding_val=float(rng.choice([29.99, 0.0, 12.5])), area_mode=bool(rng.integers(0, 2)))
+    B = int(rng.integers(1, 4))
+    sb = synth.make_batch(seed=2000 + seed, B=B, T=T, N=N, angle_inc=np.radians(inc))
+    scans = sb.scans.copy()
+    scans[rng.random(scans.shape) < 0.02] = 0.02          # near-field returns: very wide windows
+    phi = R.laser_phi(np.radians(inc), N)
+    tab = ops.phi_table(np.radians(inc), N)
+    got, dbg = ops.cutout(dev(scans), tab, return_debug=True, **kw)
+    for b in range(B):
+        want, wd = R.cutout(scans[b], phi, atan_mode="cr", return_debug=True, **kw)
+        assert np.array_equal(dbg["lo"][b].cpu().numpy(), wd["lo"]), (seed, kw)
+        assert np.array_equal(got[b].cpu().numpy(), want), (seed, kw)
+    fast = ops.cutout(dev(scans), tab, exact_values=False, **kw)
+    assert (fast - got).abs().max().item() <= 2e-5 * max(1.0, 1.0 / kw["window_depth"]) * (30.0 if not kw["centered"] else 1.0)
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_scan_preprocess(ops, seed):
+    rng = np.random.default_rng(3000 + seed)
+    N = int(rng.choice([31, 90, 225, 450, 451, 900]))
+    B = int(rng.integers(1, 40))
+    inc = float(rng.choice([0.5, 1.0, 0.25]))
+    sb = synth.make_batch(seed=4000 + seed, B=B, T=2, N=N, angle_inc=np.radians(inc),
+                          max_legs=int(rng.choice([0, 3, 6, 14])), mixed_classes=bool(rng.integers(0, 2)))
+    ped = bool(rng.integers(0, 2))
+    o, r, c = sb.det_csr(pedestrian_only=ped)
+    tab = ops.phi_table(np.radians(inc), N)
+    phi = R.laser_phi(np.radians(inc), N)
+    canonical = bool(rng.integers(0, 2))
+    labels = (1, 1, 1) if ped else (1, 2, 3)
+    out = ops.scan_preprocess(dev(sb.scans), tab, dev(sb.odom0), dev(sb.odom1), ops.DetCSR.from_numpy(o, r, c, "cuda"),
+                              canonical=canonical, out_dtype=torch.float64, labels=labels,
+                              want=("xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "exclude_mask"))
+    for b in range(B):
+        cur = sb.scans[b, -1]
+        wc, wa, wp = sb.dets[b]["wc"], sb.dets[b]["wa"], sb.dets[b]["wp"]
+        if ped:
+            wc, wa = [], []
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        flow = R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b])
+        if canonical:
+            flow = R.flow_to_canonical(flow, phi)
+        np.testing.assert_allclose(out["flow"][b].cpu().numpy(), flow, rtol=0, atol=1e-12)
+        cls, reg = R.regression_target(cur, phi, wc, wa, wp, pedestrian_only=ped)
+        assert np.array_equal(out["target_cls"][b].cpu().numpy(), cls), (seed, b)
+        np.testing.assert_allclose(out["target_reg"][b].cpu().numpy(), reg, rtol=0, atol=1e-6)
+        dyn = R.dynamic_mask(xy, wc, wa, wp)
+        assert np.array_equal(out["dyn_mask"][b].cpu().numpy().astype(np.float64), dyn), (seed, b)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_attention_and_correlation(ops, seed):
+    rng = np.random.default_rng(5000 + seed)
+    B, N = int(rng.integers(1, 4)), int(rng.choice([3, 17, 40, 64, 100, 257]))
+    E, F, w = int(rng.choice([4, 12, 32, 128])), int(rng.choice([4, 16, 56, 260])), int(rng.choice([1, 3, 7, 11, 15]))
+    ex = rng.normal(0, 0.4, (B, N, E)).astype(np.float32)
+    et = rng.normal(0, 0.4, (B, N, E)).astype(np.float32)
+    x = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    t = rng.normal(0, 1, (B, N, F)).astype(np.float32)
+    alpha = float(rng.uniform(0.1, 0.9))
+    out, band, prob = ops.spatial_attention(dev(ex), dev(et), dev(x), dev(t), alpha, w)
+    wo, wb = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
+                                 t.astype(np.float64), alpha, w)
+    np.testing.assert_allclose(band.cpu().numpy(), wb, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), wo, rtol=1e-4, atol=1e-5)
+    C, n = int(rng.choice([1, 5, 32, 70])), int(rng.choice([2, 9, 57, 64, 65, 200]))
+    K, md = int(rng.choice([1, 3, 5])), int(rng.integers(0, 8))
+    f1 = rng.integers(-3, 4, (B, C, n)).astype(np.float32)
+    f2 = rng.integers(-3, 4, (B, C, n)).astype(np.float32)
+    got = ops.band_correlation(dev(f1), dev(f2), K, md).cpu().numpy()
+    assert np.array_equal(got, R.band_correlation(f1.astype(np.float64), f2.astype(np.float64), K, md).astype(np.float32))
+
+
+def test_pedestrian_only_batch_keeps_all_classes_in_the_mask(ops):
+    """DROWBatchPreprocessor(pedestrian_only=True) like the reference's __getitem__: regression target from
+    the persons only (label 1), dynamic mask from wheelchairs, walkers and persons."""
+    from planar_optical_flow_amd.preprocess import DROWBatchPreprocessor
+    sb = synth.make_batch(seed=77, B=24, T=3, mixed_classes=True)
+    pre = DROWBatchPreprocessor(cutout_kwargs=None, pedestrian_only=True)
+    dets = pre.make_detections([d["wc"] for d in sb.dets], [d["wa"] for d in sb.dets], [d["wp"] for d in sb.dets])
+    batch = pre(dev(sb.scans), dev(sb.odom0), dev(sb.odom1), dets)
+    phi = R.laser_phi()
+    n_other = 0
+    for b in range(24):
+        cur, d = sb.scans[b, -1], sb.dets[b]
+        n_other += len(d["wc"]) + len(d["wa"])
+        cls, reg = R.regression_target(cur, phi, d["wc"], d["wa"], d["wp"], pedestrian_only=True)
+        assert np.array_equal(batch["target_cls"][b].cpu().numpy(), cls)
+        np.testing.assert_allclose(batch["target_reg"][b].cpu().numpy(), reg, rtol=0, atol=1e-6)
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        want = R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]) * R.valid_point_mask(cur)
+        assert np.array_equal(batch["exclude_mask"][b].cpu().numpy().astype(np.float64), want)
+    assert n_other > 0
