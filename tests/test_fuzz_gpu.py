@@ -127,3 +127,34 @@ def test_pedestrian_only_batch_keeps_all_classes_in_the_mask(ops):
         want = R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]) * R.valid_point_mask(cur)
         assert np.array_equal(batch["exclude_mask"][b].cpu().numpy().astype(np.float64), want)
     assert n_other > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_nms_and_polar_grid(ops, seed):
+    rng = np.random.default_rng(6000 + seed)
+    N = int(rng.choice([17, 64, 100, 450, 451, 700]))
+    inc = float(rng.choice([0.5, 1.0]))
+    B = int(rng.integers(1, 4))
+    sb = synth.make_batch(seed=7000 + seed, B=B, T=1, N=N, angle_inc=np.radians(inc))
+    scans = sb.scans[:, 0]
+    phi = R.laser_phi(np.radians(inc), N)
+    tab = ops.phi_table(np.radians(inc), N)
+    cls = rng.permutation(B * N).reshape(B, N).astype(np.float64) / (B * N)      # distinct scores
+    reg = rng.normal(0, 0.3, (B, N, 2))
+    md = float(rng.choice([0.2, 0.5, 1.5]))
+    xy, dc, num, inst = ops.nms_predicted_center(dev(scans), tab, dev(cls), dev(reg), md)
+    for b in range(B):
+        wxy, wcls, winst = R.nms_predicted_center(scans[b], phi, cls[b][:, None], reg[b], md)
+        m = int(num[b].item())
+        assert m == len(wxy), (seed, b)
+        assert np.array_equal(inst[b].cpu().numpy(), winst)
+        np.testing.assert_allclose(xy[b, :m].cpu().numpy(), wxy, rtol=0, atol=1e-12)
+        assert np.array_equal(dc[b, :m].cpu().numpy(), wcls[:, 0])
+    kw = dict(min_range=float(rng.choice([0.0, 0.5])), max_range=float(rng.choice([20.0, 29.5, 30.0])),
+              range_bin_size=float(rng.choice([0.25, 0.5, 1.0])), tsdf_clip=float(rng.choice([0.0, 1.0, 2.5])),
+              normalize=bool(rng.integers(0, 2)))
+    T_ = int(rng.integers(1, 5))
+    sbp = synth.make_batch(seed=8000 + seed, B=B, T=T_, N=N, angle_inc=np.radians(inc))
+    got = ops.polar_grid(dev(sbp.scans), **kw).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got[b], R.polar_grid(sbp.scans[b], **kw)), (seed, kw)
