@@ -260,6 +260,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         if (isarea) wt.alist[atomicAdd(&s_acount, 1)] = p;
     }
     if (LDSROWS) {
+        if (threadIdx.x == 0) s_rows[T * N] = 0.0f;      // pad word behind the last row (second lerp tap)
         if (vec_stage) {
 #pragma unroll
             for (int v = 0; v < kMaxStage; ++v) {
@@ -404,8 +405,17 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                         y = finish_value<VMODE>(a, (double)mean_a, dd);
                     }
                 } else {
-                    const float vlo = fetch(roff + lo[u]);
-                    const float vhi = fetch(roff + min(lo[u] + 1, N - 1));
+                    float vlo, vhi;
+                    if (LDSMODE == 1) {
+                        // both taps with one LDS access (adjacent words).  At lo = N-1 the second tap is the
+                        // next row's first element (or the zeroed pad word after the last row): only
+                        // idx == N-1 exactly gets there in range, with ratio 0, and 0 * finite = 0
+                        vlo = s_rows[roff + lo[u]];
+                        vhi = s_rows[roff + lo[u] + 1];
+                    } else {
+                        vlo = fetch(roff + lo[u]);
+                        vhi = fetch(roff + min(lo[u] + 1, N - 1));
+                    }
                     if (VMODE == 2) {
                         float v = fmaf((float)ratio[u], vhi - vlo, vlo);
                         const float df = (float)dd;  // exact: a float32 value
@@ -541,12 +551,12 @@ int cutout_launch(const float *scans, int B, int T, int N, const double *tab, in
     a.tile = fixed ? (kMaxWin / T > 0 ? kMaxWin / T : 1) : kMaxWin;
     if (a.tile > a.Ns) a.tile = a.Ns;
     const size_t tbl = win_table_bytes(fixed ? a.tile * T : a.tile);
-    const bool rows_in_lds = tbl + row_bytes <= 64 * 1024;
+    const bool rows_in_lds = tbl + row_bytes + 16 <= 64 * 1024;
     // otherwise: per-tile span staging with a 48 KB row buffer
     a.span_cap = (int)((48 * 1024) / ((size_t)T * sizeof(float)));
     if (a.span_cap > N) a.span_cap = N;
     const bool span_mode = !rows_in_lds && a.span_cap >= 64;
-    const size_t lds = tbl + (rows_in_lds ? row_bytes : (span_mode ? (size_t)a.span_cap * T * sizeof(float) : 0));
+    const size_t lds = tbl + (rows_in_lds ? row_bytes + 16 : (span_mode ? (size_t)a.span_cap * T * sizeof(float) : 0));
     dim3 grid((a.Ns + a.tile - 1) / a.tile, B);
     // 16-byte float4 stores / 8-byte half4 stores both need P % 4 == 0 and an aligned base
     const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
