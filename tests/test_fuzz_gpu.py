@@ -158,3 +158,57 @@ def test_fuzz_nms_and_polar_grid(ops, seed):
     got = ops.polar_grid(dev(sbp.scans), **kw).cpu().numpy()
     for b in range(B):
         assert np.array_equal(got[b], R.polar_grid(sbp.scans[b], **kw)), (seed, kw)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_segments_iou_conv(ops, seed):
+    rng = np.random.default_rng(9000 + seed)
+    # A13: cut indices bit-exact, simple features tight, fits on well conditioned segments
+    N = int(rng.choice([120, 450, 451]))
+    inc = float(rng.choice([0.5, 1.0]))
+    jump = float(rng.choice([0.3, 0.5, 0.8]))
+    sb = synth.make_batch(seed=9500 + seed, B=3, T=1, N=N, angle_inc=np.radians(inc), dropout=0.0)
+    scans = sb.scans[:, 0]
+    phi = R.laser_phi(np.radians(inc), N)
+    sid, num, feat = ops.segment_features(dev(scans), ops.phi_table(np.radians(inc), N), jump)
+    for b in range(3):
+        cuts, want = R.segment_features(scans[b], phi, jump)
+        S = len(cuts) + 1
+        assert int(num[b].item()) == S
+        ids = np.zeros(N, dtype=np.int32)
+        ids[cuts] = 1
+        assert np.array_equal(sid[b].cpu().numpy(), np.cumsum(ids))
+        got = feat[b, :S].cpu().numpy()
+        assert np.array_equal(got[:, 0], want[:, 0])
+        np.testing.assert_allclose(got[:, [1, 2, 3, 4, 8, 9]], want[:, [1, 2, 3, 4, 8, 9]], rtol=1e-9, atol=1e-12,
+                                   equal_nan=True)
+    # A16: random boxes, the reference's float32 tolerance
+    def boxes(n, s):
+        b = np.zeros((n, s), dtype=np.float32)
+        b[:, :2] = rng.uniform(-1.5, 1.5, (n, 2))
+        if s == 5:
+            b[:, 2:4] = rng.uniform(0.2, 2.0, (n, 2))
+            b[:, 4] = rng.uniform(-np.pi, np.pi, n)
+        else:
+            b[:, 2] = rng.uniform(-0.5, 0.5, n)
+            b[:, 3:6] = rng.uniform(0.2, 2.0, (n, 3))
+            b[:, 6] = rng.uniform(-np.pi, np.pi, n)
+        return b
+    for s, is3d in ((5, False), (7, True)):
+        bx, qx = boxes(int(rng.integers(1, 40)), s), boxes(int(rng.integers(1, 40)), s)
+        crit = int(rng.choice([-1, 0, 1]))
+        got = ops.rotate_iou(dev(bx), dev(qx), is_3d=is3d, criterion=crit).cpu().numpy()
+        np.testing.assert_allclose(got, R.rotate_iou(bx, qx, criterion=crit, is_3d=is3d), rtol=0, atol=2e-5)
+    # N2 layer: random channel / length / sequence counts, integer data exact
+    S, Ci, Co, L = int(rng.integers(1, 20)), int(rng.integers(1, 70)), int(rng.integers(1, 140)), int(rng.integers(1, 30))
+    pool = bool(rng.integers(0, 2)) and L % 2 == 0 and L >= 2
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randint(-3, 4, (S, Ci, L), generator=g).float().cuda()
+    w = torch.randint(-2, 3, (Co, Ci, 3), generator=g).float().cuda()
+    scale = torch.full((Co,), 0.5).cuda()
+    shift = torch.randint(-3, 4, (Co,), generator=g).float().cuda()
+    got = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, pool=pool, negative_slope=0.25)
+    y = torch.nn.functional.conv1d(x.double(), w.double(), None, padding=1) * 0.5 + shift.double()[None, :, None]
+    y = torch.nn.functional.leaky_relu(y, 0.25)
+    want = (torch.max_pool1d(y, 2) if pool else y).float()
+    assert torch.equal(got, want), (S, Ci, Co, L, pool)
