@@ -226,13 +226,28 @@ def main():
                     step(i, phases=2)
                 main.wait_stream(side2)
 
+    # K or W need not be multiples of the ring: the remainder steps get their own captured graph
+    # (an eager launch costs tens of microseconds of Python per step, several times the kernel)
+    rem_graphs = {}
+    if graph is not None and not a.pipeline:
+        for rem in sorted({a.steps % a.ring, a.warmup % a.ring} - {0}):
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for i in range(rem):
+                    step(i)
+            rem_graphs[rem] = gr
+
     def run(k):
         if graph is not None:
             full, rem = divmod(k, a.ring)
             for _ in range(full):
                 graph.replay()
-            for i in range(rem):
-                step(i)
+            if rem in rem_graphs:
+                rem_graphs[rem].replay()
+            else:
+                for i in range(rem):
+                    step(i)
         else:
             for i in range(k):
                 step(i)
