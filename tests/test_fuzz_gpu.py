@@ -212,3 +212,64 @@ def test_fuzz_segments_iou_conv(ops, seed):
     y = torch.nn.functional.leaky_relu(y, 0.25)
     want = (torch.max_pool1d(y, 2) if pool else y).float()
     assert torch.equal(got, want), (S, Ci, Co, L, pool)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_standalone_geometry_and_store(ops, seed):
+    """A3 / A5 / A12 stand-alone entry points and the N1 store kernels on random shapes."""
+    rng = np.random.default_rng(11000 + seed)
+    B, N = int(rng.integers(1, 6)), int(rng.choice([7, 64, 450, 451]))
+    inc = float(rng.choice([0.5, 1.0]))
+    phi = R.laser_phi(np.radians(inc), N)
+    tab = ops.phi_table(np.radians(inc), N)
+    xy = rng.uniform(-20, 20, (B, N, 2))
+    o0 = np.column_stack([rng.uniform(-3, 3, (B, 2)), rng.uniform(-3, 3, B)])
+    o1 = o0 + np.column_stack([rng.uniform(-0.1, 0.1, (B, 2)), rng.uniform(-0.05, 0.05, B)])
+    for kind, fn in ((ops.FLOW_DISPLACEMENT, R.displacement_from_odometry), (ops.FLOW_VELOCITY, R.velocity_from_odometry)):
+        for canonical in (False, True):
+            got = ops.flow_from_xy(dev(xy), dev(o0), dev(o1), flow_kind=kind, canonical=canonical, tab=tab).cpu().numpy()
+            for b in range(B):
+                want = fn(xy[b], o0[b], o1[b])
+                if canonical:
+                    want = R.flow_to_canonical(want, phi)
+                np.testing.assert_allclose(got[b], want, rtol=0, atol=1e-11)
+    # A5 both ways
+    r = rng.uniform(0.5, 20, (B, N)).astype(np.float32)
+    dr, dp = rng.uniform(0.5, 20, (B, N)), rng.uniform(-1.9, 1.9, (B, N))
+    dx, dy = ops.det_to_canonical(dev(r), tab, dev(dr), dev(dp))
+    wx, wy = R.det_to_canonical(r.astype(np.float64), phi[None], dr, dp)
+    np.testing.assert_allclose(dx.cpu().numpy(), wx, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(dy.cpu().numpy(), wy, rtol=0, atol=1e-12)
+    rr, pp = ops.canonical_to_det(dev(r), tab, dx, dy)
+    wr, wp = R.canonical_to_det(r.astype(np.float64), phi[None], wx, wy)
+    np.testing.assert_allclose(rr.cpu().numpy(), wr, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(pp.cpu().numpy(), wp, rtol=0, atol=1e-12)
+    # A12
+    pred = rng.normal(0, 1, (B, N, 2)).astype(np.float32)
+    tgt = rng.normal(0, 1, (B, N, 2)).astype(np.float32)
+    mask = (rng.random((B, N)) < 0.7).astype(np.float32)
+    e, a, c = ops.flow_errors(dev(pred), dev(tgt))
+    we, wa = R.epe_aae_eval(pred.astype(np.float64), tgt.astype(np.float64))
+    np.testing.assert_allclose((e / c).cpu().numpy(), we, rtol=1e-5)
+    np.testing.assert_allclose((a / c).cpu().numpy() * 180 / np.pi, wa, rtol=1e-4)
+    e, a, c = ops.flow_errors(dev(pred), dev(tgt), dev(mask))
+    if mask.sum() > 0:
+        np.testing.assert_allclose((e.sum() / c.sum()).item(), R.epe_masked(pred.astype(np.float64), tgt.astype(np.float64), mask), rtol=1e-5)
+    # N1: window gather and time association on a random store
+    S = int(rng.integers(12, 60))
+    scans_all = rng.uniform(0.3, 25, (S, N)).astype(np.float32)
+    t_s = np.sort(rng.uniform(0, 10, S)).astype(np.float32)
+    O = int(rng.integers(5, 90))
+    t_o = np.sort(rng.uniform(0, 10, O)).astype(np.float32)
+    odoms = rng.uniform(-5, 5, (O, 3)).astype(np.float32)
+    ns, dist, stride = int(rng.integers(1, 7)), int(rng.integers(0, 7)), int(rng.integers(1, 4))
+    idx = rng.integers(0, S, 9).astype(np.int32)
+    win, rc, rp = ops.gather_windows(dev(scans_all), dev(np.zeros(9, np.int32)), dev(idx), ns, dist, stride)
+    od0, od1, i0, i1 = ops.associate_odometry(dev(t_s), dev(t_o), dev(odoms), dev(np.zeros(9, np.int32)),
+                                              dev(np.full(9, O, np.int32)), rc, rp)
+    for k in range(9):
+        inds = R.window_indices(int(idx[k]), ns, dist, stride)
+        assert np.array_equal(win[k].cpu().numpy(), np.vstack((scans_all[inds], scans_all[idx[k]])))
+        w0, w1 = R.associate_odometry(t_o, t_s, int(idx[k]), inds)
+        assert (int(i0[k]), int(i1[k])) == (w0, w1)
+        assert np.array_equal(od1[k].cpu().numpy(), odoms[w1].astype(np.float64))
