@@ -309,6 +309,7 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
             raise ValueError("out has the wrong shape")
     entry = "pof_cutout_ex" if out_dtype == torch.float32 else "pof_cutout_f16"
     dbg = torch.empty((B, P, T, Ns), dtype=torch.int32, device=scans.device) if return_debug else None
+    dbg_area = None
     with torch.cuda.device(scans.device):
         step = 65535
         for s in range(0, B, step):

@@ -123,6 +123,8 @@ class DROWDeviceDataset:
         """The collated batch dict of ``collate_batch([ds[i] for i in indices])``: device tensors for the
         tensor keys (scans, input, target_cls, target_reg, target_flow, exclude_mask), python lists for
         the annotation keys."""
+        if len(indices) == 0:
+            raise ValueError("get_batch needs at least one sample index")
         smp = [self._samples[i] for i in indices]
         dev = self.device
         idx = torch.as_tensor(np.asarray(indices, dtype=np.int64), device=dev)
