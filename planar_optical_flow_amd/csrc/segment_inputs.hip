@@ -78,8 +78,9 @@ __global__ __launch_bounds__(kSegThreads) void segment_inputs_kernel(SegArgsIn a
     const int n = s_n;
     int m = min(n, kSegCap);
     if (n > kSegCap) {
-        // pass 2: only a random subset of size M is needed -> keep the ~2048 smallest hashes
-        const uint32_t thr = (uint32_t)(4294967296.0 * (2048.0 / (double)n));
+        // pass 2: only a random subset of size M <= 1024 is needed -> keep the ~3072 smallest hashes
+        // (binomial spread ~55: never fewer than M, never more than the list holds)
+        const uint32_t thr = (uint32_t)(4294967296.0 * (3072.0 / (double)n));
         for (int i0 = 0; i0 < a.Np; i0 += kSegThreads) {
             const int i = i0 + tid;
             if (i < a.Np && inside(i)) {
@@ -127,6 +128,7 @@ __global__ __launch_bounds__(kSegThreads) void segment_inputs_kernel(SegArgsIn a
         int src;
         if (n > a.M) src = j;
         else src = (j < n * rep) ? j / rep : (j - n * rep) / rep;   // rows of np.repeat(seg, rep), then its first rows again
+        src = min(src, m - 1);                                      // never past the sorted candidates
         const int pi = (int)(uint32_t)s_key[src];
         for (int d = 0; d < D; ++d) x[j * (D + 1) + d] = (float)(a.points[(long long)pi * D + d] - c[d]);
         x[j * (D + 1) + D] = (float)ori;
@@ -207,7 +209,7 @@ extern "C" int pof_segment_inputs(const double *points, int Np, int D, const dou
     if (!points || !centers || !oris || !x || !count) return POF_E_BADARG;
     if (Np < 0 || S < 0 || input_size < 1 || !(radius >= 0.0)) return POF_E_BADARG;
     if (D < 2 || D > 3) return POF_E_SHAPE;
-    if (input_size > 2048) return POF_E_SHAPE;      // the thinning pass keeps ~2048 candidates
+    if (input_size > 1024) return POF_E_SHAPE;      // the thinning pass keeps ~3072 candidates
     if (S == 0) return POF_OK;
     SegArgsIn a;
     a.points = points; a.centers = centers; a.oris = oris; a.Np = Np; a.D = D; a.M = input_size;
