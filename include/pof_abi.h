@@ -391,6 +391,17 @@ int pof_polar_grid(const float *scans, int B, int T, int N, double min_range, do
 int pof_csv_shape(const char *path, long long *rows, int *cols);
 int pof_csv_read_f64(const char *path, long long rows, int cols, double *out, int threads);
 
+/* ----------------------------------------------------------------------
+ * N4, host side: LZF block decoder for `DATA binary_compressed` .pcd files.
+ * Replaces lzf.decompress(compressed_data, uncompressed_size) in the vendored
+ * pypcd (src/data_handle/_pypcd.py:249-264), which JRDBHandle._load_pointcloud
+ * (src/data_handle/jrdb_handle.py:293-305) goes through.  Returns the number of
+ * bytes written to out, or -1 when the stream is malformed, refers before the
+ * start of the output or would exceed out_cap (nothing outside [out, out+out_cap)
+ * is touched).
+ * ---------------------------------------------------------------------- */
+long long pof_lzf_decompress(const void *in, long long in_len, void *out, long long out_cap);
+
 #ifdef __cplusplus
 }
 #endif

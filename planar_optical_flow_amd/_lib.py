@@ -58,6 +58,7 @@ SIGNATURES = {
     "pof_polar_grid": (_i, [_p, _i, _i, _i, _d, _d, _d, _d, _i, _p, _p]),
     "pof_csv_shape": (_i, [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "pof_csv_read_f64": (_i, [C.c_char_p, _ll, _i, _p, _i]),
+    "pof_lzf_decompress": (_ll, [_p, _ll, _p, _ll]),
 }
 
 

@@ -159,3 +159,43 @@ extern "C" int pof_csv_read_f64(const char *path, long long rows, int cols, doub
     }
     return bad.load() ? POF_E_SHAPE : POF_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------
+// LZF block decoder for `DATA binary_compressed` .pcd payloads (the reference reaches liblzf
+// through python-lzf in src/data_handle/_pypcd.py:249-264).  Control byte c < 32: c + 1 literal
+// bytes follow; otherwise a back reference of (c >> 5) + 2 bytes (a 7 in the top bits adds the
+// next byte to the length) at distance ((c & 31) << 8 | next byte) + 1.  Every read and write is
+// bounds checked; a reference may overlap its own output (run-length use), so it is copied bytewise.
+// ---------------------------------------------------------------------------------------
+extern "C" long long pof_lzf_decompress(const void *in_, long long in_len, void *out_, long long out_cap)
+{
+    if ((!in_ && in_len) || (!out_ && out_cap) || in_len < 0 || out_cap < 0) return -1;
+    const unsigned char *ip = static_cast<const unsigned char *>(in_), *ie = ip + in_len;
+    unsigned char *out = static_cast<unsigned char *>(out_);
+    long long op = 0;
+    while (ip < ie) {
+        unsigned c = *ip++;
+        if (c < 32) {
+            long long run = c + 1;
+            if (ie - ip < run || out_cap - op < run) return -1;
+            std::memcpy(out + op, ip, run);
+            ip += run;
+            op += run;
+        } else {
+            long long len = c >> 5;
+            if (len == 7) {
+                if (ip >= ie) return -1;
+                len += *ip++;
+            }
+            if (ip >= ie) return -1;
+            long long dist = ((long long)(c & 31) << 8 | *ip++) + 1;
+            len += 2;
+            if (dist > op || out_cap - op < len) return -1;
+            const unsigned char *ref = out + op - dist;
+            for (long long k = 0; k < len; ++k) out[op + k] = ref[k];
+            op += len;
+        }
+    }
+    return op;
+}

@@ -5,7 +5,7 @@ appends a random input angle, randomly drops a quarter of the points (training) 
 to ``input_size`` rows -- in DataLoader workers, one sample at a time.  Here all segments live
 in one point pool in HBM (CSR offsets) and a whole batch is ONE launch of
 ``pof_segment_resample``.  The constructor takes the frames ``JRDBHandle`` yields
-(``dict(segments, boxes, dets_center)``; JRDB file parsing is host I/O and not rebuilt) and
+(``dict(segments, boxes, dets_center)``: a ``jrdb_handle.JRDBHandle`` or any iterable of such dicts) and
 repeats the reference's bookkeeping: size filter, orientation wrap, neighbour annotations, one
 augmented copy per sample in training.
 

@@ -371,6 +371,39 @@ def main():
     import shutil
     shutil.rmtree(tmp)
 
+    # ---------------- N3, file side: the reference's JRDBHandle on a synthetic JRDB tree ---------
+    # tests/jrdb_tree.py writes the tree from a seed (ascii and binary .pcd; the LZF encoding needs
+    # python-lzf, which this image lacks, and is covered by round-trip tests instead); the reference's
+    # handle indexes and reads it.  3-D mode: every labelled frame.  2-D mode: only the frame whose
+    # annotation list is empty -- the reference's 2-D branch raises on the first annotation
+    # (jrdb_handle.py:250-252 calls list.append with five arguments), so `points` is what it can give.
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import jrdb_tree
+    import src.data_handle.jrdb_handle as ref_jh
+    tmp = tempfile.mkdtemp(prefix="pof_jrdb_")
+    val_names = list(ref_jh._JRDB_VAL_SEQUENCES)
+    labelled = jrdb_tree.make_tree(tmp, val_names, seed=11)
+    gj = {"val_sequences": np.array(val_names), "train_sequences": np.array(ref_jh._JRDB_TRAIN_SEQUENCES),
+          "labelled_seq": np.array([a for a, _, _ in labelled]), "labelled_file": np.array([b for _, b, _ in labelled])}
+    h3 = ref_jh.JRDBHandle("val", {"data_dir": tmp, "radius_segment": 0.7, "perturb": 0.1, "is_3d": True})
+    gj["len"] = np.array(len(h3))
+    for i in range(len(h3)):
+        np.random.seed(1000 + i)
+        fr = h3[i]
+        gj["f%d_points" % i] = fr["points"]
+        gj["f%d_boxes" % i] = np.asarray(fr["boxes"], dtype=np.float64)
+        gj["f%d_centers" % i] = np.asarray(fr["dets_center"], dtype=np.float64)
+        gj["f%d_seg_len" % i] = np.array([len(sg) for sg in fr["segments"]], dtype=np.int32)
+        gj["f%d_seg_pts" % i] = np.concatenate(fr["segments"]) if len(fr["segments"]) else np.zeros((0, 3), np.float32)
+        gj["f%d_url" % i] = np.array(fr["pointclouds"]["upper_velodyne"]["url"])
+    h2 = ref_jh.JRDBHandle("test", {"data_dir": tmp, "radius_segment": 0.7, "perturb": 0.1, "is_3d": False})
+    empty = [i for i, (_, _, n) in enumerate(labelled) if n == 0]
+    gj["empty_index"] = np.array(empty)
+    for i in empty:
+        gj["laser%d_points" % i] = h2[i]["points"]
+    np.savez_compressed(os.path.join(OUT, "jrdb_files.npz"), **gj)
+    shutil.rmtree(tmp)
+
     # ---------------- N4: scans_to_polar_grid -------------------------------------------------
     gp = {}
     sbp = synth.make_batch(seed=81, B=2, T=5)
