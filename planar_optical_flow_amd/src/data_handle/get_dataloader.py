@@ -4,8 +4,9 @@
 The reference wraps ``JRDBBoxRegressionDataset`` in a ``torch.utils.data.DataLoader`` with worker
 processes; here a batch is one kernel launch, so the loader is a plain iterable that draws index
 batches (shuffled per epoch when asked) and calls ``dataset.get_batch`` -- ``num_workers`` is
-accepted and ignored.  JRDB file parsing is not rebuilt: ``dataset_cfg["frames"]`` carries the
-frames ``JRDBHandle`` would yield (dicts with ``segments``, ``boxes``, ``dets_center``).
+accepted and ignored.  The frames come from ``JRDBHandle(split, dataset_cfg)`` reading the JRDB tree under
+``dataset_cfg["data_dir"]``, or -- optional -- from ``dataset_cfg["frames"]`` (already parsed dicts with
+``segments``, ``boxes``, ``dets_center``).
 """
 import numpy as np
 
@@ -31,7 +32,5 @@ class DeviceBatchLoader:
 def get_dataloader(split, batch_size, num_workers, shuffle, dataset_cfg):
     if "JRDB" not in dataset_cfg["data_dir"]:
         raise RuntimeError("Unknown dataset {}.".format(dataset_cfg.get("name", dataset_cfg["data_dir"])))
-    if "frames" not in dataset_cfg:
-        raise FileNotFoundError("JRDB parsing is out of scope: pass the parsed frames as dataset_cfg['frames']")
-    ds = JRDBBoxRegressionDataset(split, dataset_cfg, dataset_cfg["frames"])
+    ds = JRDBBoxRegressionDataset(split, dataset_cfg, dataset_cfg.get("frames"))
     return DeviceBatchLoader(ds, batch_size, shuffle=shuffle)

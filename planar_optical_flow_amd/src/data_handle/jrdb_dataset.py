@@ -38,7 +38,10 @@ def _rot2_f32(phi):
 
 
 class JRDBBoxRegressionDataset:
-    def __init__(self, split, cfg, frames, device="cuda", rng=None, seed=0):
+    def __init__(self, split, cfg, frames=None, device="cuda", rng=None, seed=0):
+        if frames is None:              # the reference's two-argument form: read the JRDB tree under cfg["data_dir"]
+            from .jrdb_handle import JRDBHandle
+            frames = JRDBHandle(split, cfg, device=device, rng=rng)
         self.input_size, self.is_3d, self.mode = cfg["input_size"], cfg["is_3d"], split
         self.augmentation_kwargs = cfg["augmentation_kwargs"]
         self._rng = np.random if rng is None else rng
