@@ -392,6 +392,32 @@ int pof_csv_shape(const char *path, long long *rows, int *cols);
 int pof_csv_read_f64(const char *path, long long rows, int cols, double *out, int threads);
 
 /* ----------------------------------------------------------------------
+ * N4: boosted decision stumps of the legacy person-detection baseline.
+ * pof_stump_search replaces BoostedFeatureDetector.simple_classifier
+ * (src/depracted/model/adaboost_person_det.py:283-347) for all D feature
+ * dimensions in one launch: X [rows][D] float64, Y [rows] (+1 / -1), the n
+ * samples are rows index[0..n) (index NULL: rows 0..n-1; 2 <= n <= 2048,
+ * duplicates allowed -- the boosting loop samples with replacement).  Per
+ * dimension d: n_thresh[d] = number of threshold candidates (midpoints of
+ * sorted neighbours of opposite class), min_err[d] / max_err[d] = smallest /
+ * largest count of samples misclassified by "x > theta -> +1" over the
+ * candidates, theta_min[d] / theta_max[d] = the FIRST candidate (ascending)
+ * reaching it (-1 / 0.0 when there is no candidate).  Equal feature values
+ * keep their sample order (the reference's np.argsort leaves that order to the
+ * sort implementation).  X must be finite.
+ * pof_stump_vote replaces BoostedFeatureDetector.eval (:349-378): result[i] =
+ * sum_k alpha[k] * (X[i][dim[k]-1] > theta[k] ? +1 : -1) accumulated in k order
+ * in float64, label[i] = sign(result[i]) (label may be NULL); dim is 1-based,
+ * 0 addresses the last column (an unused round of the reference's K x 2
+ * parameter table).
+ * ---------------------------------------------------------------------- */
+int pof_stump_search(const double *X, const double *Y, long long rows, const int *index, int n, int D,
+                     int *min_err, double *theta_min, int *max_err, double *theta_max, int *n_thresh,
+                     pof_stream_t stream);
+int pof_stump_vote(const double *X, long long N, int D, const int *dim, const double *theta,
+                   const double *alpha, int K, double *result, double *label, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N4, host side: LZF block decoder for `DATA binary_compressed` .pcd files.
  * Replaces lzf.decompress(compressed_data, uncompressed_size) in the vendored
  * pypcd (src/data_handle/_pypcd.py:249-264), which JRDBHandle._load_pointcloud

@@ -59,6 +59,8 @@ SIGNATURES = {
     "pof_csv_shape": (_i, [C.c_char_p, C.POINTER(C.c_longlong), C.POINTER(C.c_int)]),
     "pof_csv_read_f64": (_i, [C.c_char_p, _ll, _i, _p, _i]),
     "pof_lzf_decompress": (_ll, [_p, _ll, _p, _ll]),
+    "pof_stump_search": (_i, [_p, _p, _ll, _p, _i, _i, _p, _p, _p, _p, _p, _p]),
+    "pof_stump_vote": (_i, [_p, _ll, _i, _p, _p, _p, _i, _p, _p, _p]),
 }
 
 

@@ -101,3 +101,29 @@ if "f16" in which:
         ms = timeit(lambda: ops.spatial_attention(ex, et, x, t, 0.5, 11, out=out), iters=10)
         per = 3 * N * F * 2 + 2 * N * E * 4 + 2 * N * 11 * 4
         print("attn f16 B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
+
+if "boost" in which:
+    # N4: boosted stumps.  Device rounds vs the NumPy restatement (which is already far faster than the
+    # reference's interpreted per-sample loops) on a segment table of realistic size.
+    import time
+    from oracle import ref_numpy as R
+    from planar_optical_flow_amd.src.depracted.model.adaboost_person_det import BoostedFeatureDetector
+    rng = np.random.default_rng(0)
+    N, D, K, ns = 50000, 12, 60, 200
+    X = rng.normal(size=(N, D))
+    Y = np.where(X @ rng.normal(size=D) + 1.5 * rng.normal(size=N) > 0, 1.0, -1.0)
+    BoostedFeatureDetector(rng=np.random.default_rng(5)).adaboost(X[:1000], Y[:1000], 2, ns)      # warm-up
+    det = BoostedFeatureDetector(rng=np.random.default_rng(1))
+    t0 = time.time(); a, p = det.adaboost(X, Y, K, ns); torch.cuda.synchronize(); t1 = time.time()
+    print("adaboost HIP   N=%d D=%d K=%d nSamples=%d: %.3f s (%.2f ms/round)" % (N, D, K, ns, t1 - t0, (t1 - t0) / K * 1e3))
+    t0 = time.time(); a2, p2 = R.adaboost(X, Y, 6, ns, rng=np.random.default_rng(1)); t1 = time.time()
+    print("adaboost NumPy restatement, 6 rounds: %.3f s (%.1f ms/round)" % (t1 - t0, (t1 - t0) / 6 * 1e3))
+    assert np.array_equal(a[:6], a2) and np.array_equal(p[:6], p2)
+    Xd = torch.from_numpy(X).cuda()
+    ms = timeit(lambda: det.eval(Xd, a, p))
+    print("eval (stump vote) N=%d K=%d: %.3f ms incl. D2H" % (N, K, ms))
+    idx = torch.from_numpy(rng.integers(0, N, 2048).astype(np.int32)).cuda()
+    Yd = torch.from_numpy(Y).cuda()
+    for n in (200, 2048):
+        ms = timeit(lambda: det._search(Xd, Yd, idx[:n].contiguous(), n))
+        print("stump search n=%d D=%d: %.3f ms incl. D2H of the %d results" % (n, D, ms, 5 * D))

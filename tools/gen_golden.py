@@ -404,6 +404,86 @@ def main():
     np.savez_compressed(os.path.join(OUT, "jrdb_files.npz"), **gj)
     shutil.rmtree(tmp)
 
+    # ---------------- N4 + A13: the legacy boosted-stump baseline ---------------------------------
+    # src/depracted/model/adaboost_person_det.py is a script: it parses --cfg at import and imports
+    # src.data_handle.depracted.drow_handle, a module the reference repository does not contain.  Both
+    # are satisfied harness-side (an argv with a throw-away yaml, an empty module with a DROWHandle
+    # name) so that its classes can be driven directly; none of them touches the placeholder.
+    for modname in ("src.data_handle.depracted", "src.data_handle.depracted.drow_handle"):
+        sys.modules[modname] = types.ModuleType(modname)
+    sys.modules["src.data_handle.depracted.drow_handle"].DROWHandle = object
+    tmp = tempfile.mkdtemp(prefix="pof_ada_")
+    with open(os.path.join(tmp, "ada.yaml"), "w") as f:
+        f.write("tag: ''\n")
+    argv, sys.argv = sys.argv, ["adaboost_person_det", "--cfg", os.path.join(tmp, "ada.yaml")]
+    import src.depracted.model.adaboost_person_det as ada
+    sys.argv = argv
+    shutil.rmtree(tmp)
+    ga = {}
+    det = ada.BoostedFeatureDetector()
+    rng = np.random.default_rng(2024)
+    # (a) simple_classifier on tie-free feature tables, one of them resampled with replacement
+    shapes = [(40, 3), (200, 14), (333, 6), (64, 1), (200, 9), (120, 5)]
+    ga["sc_cases"] = np.array(len(shapes))
+    for q, (n, D) in enumerate(shapes):
+        X = rng.normal(size=(n, D)) * rng.uniform(0.5, 20, D)
+        Y = np.where(X[:, q % D] * 0.7 + rng.normal(size=n) * X[:, q % D].std() * 0.6 > 0.1, 1.0, -1.0)
+        if q == 4:                                  # a boosting round: 200 draws out of 90 rows
+            pick = rng.integers(0, 90, n)
+            X, Y = X[pick], Y[pick]
+            ga["sc%d_pick" % q] = pick
+        if q == 5:                                  # inverted relation: the 1 - error branch wins
+            Y = -Y
+        jj, th = det.simple_classifier(X, Y.reshape(-1, 1))
+        ga["sc%d_X" % q], ga["sc%d_Y" % q] = X, Y
+        ga["sc%d_out" % q] = np.array([jj, th], dtype=np.float64)
+    # (b) adaboost + eval, seeded global state; the second table separates early (error < 0.1 -> alpha = 1, stop)
+    for q, (N, D, K, ns, noise) in enumerate([(600, 8, 12, 150, 0.8), (400, 5, 6, 100, 0.02)]):
+        X = rng.normal(size=(N, D))
+        Y = np.where(X[:, 2] + 0.5 * X[:, 0] * (q == 0) + noise * rng.normal(size=N) > 0.0, 1.0, -1.0)
+        np.random.seed(50 + q)
+        alphaK, para = det.adaboost(X, Y.reshape(-1, 1), K, ns)
+        labels, result = det.eval(X, alphaK, para)
+        ga["ab%d_X" % q], ga["ab%d_Y" % q] = X, Y
+        ga["ab%d_cfg" % q] = np.array([K, ns, 50 + q])
+        ga["ab%d_alpha" % q], ga["ab%d_para" % q] = alphaK, para
+        ga["ab%d_labels" % q], ga["ab%d_result" % q] = labels, result
+    # (c) nms_predicted_center with distinct predictions
+    segs = [[rng.normal(size=(int(rng.integers(3, 9)), 2)) * 0.1 + rng.uniform(-3, 3, 2), 1.0] for _ in range(25)]
+    preds = rng.permutation(25).astype(np.float64) - 12.5
+    scores = rng.uniform(-0.5, 2.0, 25)
+    sg, pr, sc = ada.nms_predicted_center(segs, preds.copy(), scores.copy(), min_dist=1.0)
+    ga["nms_seg_len"] = np.array([len(x[0]) for x in segs])
+    ga["nms_seg_pts"] = np.concatenate([x[0] for x in segs])
+    ga["nms_preds"], ga["nms_scores"] = preds, scores
+    ga["nms_out_first_pt"] = np.array([x[0] for x in sg])
+    ga["nms_out_preds"], ga["nms_out_scores"] = pr, sc
+    # (d) A13: scan_to_segments + compute_feature of the reference's Dataset on seeded scans
+    phi = u.get_laser_phi()
+    scans_a = 6.0 + 0.4 * np.sin(np.arange(450) / 40.0)[None] + 0.01 * rng.normal(size=(3, 450))
+    for b in range(3):                              # legs / boxes in front of a wall: >= 4 segments of > 2 points
+        at = 10
+        while at < 420:
+            span = int(rng.integers(3, 26))
+            scans_a[b, at:at + span] = rng.uniform(1.5, 4.0) + 0.05 * np.cos(np.linspace(-1.5, 1.5, span)) \
+                + 0.004 * rng.normal(size=span)
+            at += span + int(rng.integers(1, 40))
+    dsa = ada.Dataset.__new__(ada.Dataset)
+    dsa.scans_data = []
+    for b in range(3):
+        scan = scans_a[b]
+        segs_b = np.split(np.array(u.rphi_to_xy(scan, phi)).T,
+                          np.clip(np.where(np.abs(scan[1:] - scan[:-1]) >= 0.5)[0] + 1, 0, len(scan) - 1))
+        big = [sgm for sgm in segs_b if len(sgm) > 2]
+        wps = [big[i].mean(axis=0) + 0.05 for i in range(0, len(big), 3)]       # annotations near every third segment
+        segments, labels, cut_ids = dsa.scan_to_segments(scan, phi, wps)
+        dsa.scans_data.append([[[sgm, lb] for sgm, lb in zip(segments, labels) if len(sgm) > 2], cut_ids, scan, 0.1 * b])
+        ga["ft%d_scan" % b], ga["ft%d_wps" % b] = scan, np.array(wps)
+        ga["ft%d_cut_ids" % b], ga["ft%d_labels_all" % b] = cut_ids, labels
+    for b in range(3):
+        ga["ft%d_features" % b] = np.array(dsa.compute_feature(dsa.scans_data[b], b), dtype=np.float64).reshape(-1, 15)
+    np.savez_compressed(os.path.join(OUT, "adaboost.npz"), **ga)
+
     # ---------------- N4: scans_to_polar_grid -------------------------------------------------
     gp = {}
     sbp = synth.make_batch(seed=81, B=2, T=5)
