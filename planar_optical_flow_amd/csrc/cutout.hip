@@ -504,6 +504,14 @@ void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool 
 }  // namespace
 
 namespace {
+// Clears the per-sample area maxima.  A kernel rather than hipMemsetAsync: as a graph node the 4-byte memset of
+// a one-sample batch hung the second replay of a captured streaming step on ROCm 7.2 (tools/diag_stream.py).
+__global__ void clear_area_kernel(int32_t *s_area, int B)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) s_area[i] = 0;
+}
+
 int cutout_launch(const float *scans, int B, int T, int N, const double *tab, int stride, int centered, int fixed,
                   double window_width, double window_depth, int num_cutout_pts, double padding_val, int area_mode,
                   int value_mode, float *out32, _Float16 *out16, int32_t *workspace, int32_t *dbg_lo,
@@ -537,7 +545,7 @@ int cutout_launch(const float *scans, int B, int T, int N, const double *tab, in
     a.out = out32; a.out16 = out16; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
-        if (hipMemsetAsync(workspace, 0, (size_t)B * sizeof(int32_t), s) != hipSuccess) return POF_E_LAUNCH;
+        clear_area_kernel<<<(B + 255) / 256, 256, 0, s>>>(workspace, B);
         const int windows = (fixed ? T : 1) * a.Ns;
         int chunks = (windows + kThreads - 1) / kThreads;
         // enough workgroups to fill the chip at small B, at most one window per lane

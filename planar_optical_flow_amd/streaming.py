@@ -1,0 +1,93 @@
+"""Streaming DR-SPAAM inference as one hipGraph replay per scan.
+
+The reference's deployment mode is ``SpatialDROW.forward(x, testing=True, fea_template=...)``
+(src/depracted/model/dr_spaam.py:243-262): every new scan is cut out, run through the first two trunk
+blocks, fused with the running template by the attention gate and classified; the fused template is fed
+back on the next call: ~30 kernel launches per scan.  ``StreamingDetector`` keeps the scan, the template and
+the outputs in fixed device buffers, captures the steady-state step once and replays it, so the host thread
+issues one graph launch per scan instead of thirty kernel launches.  Measured on MI355X
+(tools/bench_stream.py): 0.93 ms per scan at one sensor, 2.13 ms at eight -- the same as the eager step, whose
+launches already run ahead of the GPU; the step is bound by the per-layer latency of the small grids, and the
+replay's gain is the freed host thread, not GPU time.  Outputs are bit-identical to the eager step.
+"""
+import torch
+
+from . import ops
+
+_DEFAULT_CUTOUT = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+                       padding_val=29.99, area_mode=True)
+
+
+class StreamingDetector:
+    """``det = StreamingDetector(model)``; ``pred_cls, pred_reg = det(scan)`` per incoming scan.
+
+    model: an eval-mode ``SpatialDROW`` on the GPU (``fuse_for_inference()`` is applied).  scan: [N] or [B, N]
+    ranges (B independent sensors advance in lock-step).  The returned tensors are the detector's fixed output
+    buffers -- valid until the next call; ``.clone()`` to keep them.  ``feat_fused`` (the window similarities
+    of the last step, input of the flow head) and ``template`` are attributes.  ``reset()`` forgets the
+    template, as at the start of a sequence.  ``graph=False`` runs the same step eagerly (reference for
+    tests and timing)."""
+
+    def __init__(self, model, num_pts=450, batch=1, angle_inc=None, cutout_kwargs=None, graph=True, device="cuda"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StreamingDetector needs the GPU (no CPU path)")
+        self.model = model.to(device).eval()
+        self.model.fuse_for_inference()
+        self.kw = dict(_DEFAULT_CUTOUT if cutout_kwargs is None else cutout_kwargs)
+        self.B, self.N = int(batch), int(num_pts)
+        dev = next(self.model.parameters()).device
+        self.tab = ops.phi_table(num_pts=self.N, device=dev) if angle_inc is None \
+            else ops.phi_table(angle_inc, self.N, device=dev)
+        self._scan = torch.zeros((self.B, 1, self.N), dtype=torch.float32, device=dev)
+        self._use_graph = bool(graph)
+        self._graph = None
+        self.template = None            # fixed buffer once the first scan has been seen
+        self._have_template = False
+        self.feat_fused = self.pred_cls = self.pred_reg = None
+
+    def reset(self):
+        self._have_template = False
+
+    # one step on the static buffers; `first` = no template yet
+    def _step(self, first):
+        x = ops.cutout(self._scan, self.tab, **self.kw)
+        with torch.no_grad():
+            cls, reg, tmpl, fused = self.model(x, testing=True, fea_template=None if first else self.template)
+        return cls, reg, tmpl, fused
+
+    def _store_template(self, tmpl):
+        if self.template is None:
+            self.template = tmpl.clone()              # allocated once: the captured graph holds its address
+        else:
+            self.template.copy_(tmpl)
+
+    def _capture(self):
+        side = torch.cuda.Stream(device=self._scan.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):                 # warm-up off the capture: library handles, lazy inits
+            for _ in range(2):
+                self._step(False)
+        torch.cuda.current_stream().wait_stream(side)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            cls, reg, tmpl, fused = self._step(False)
+            self.template.copy_(tmpl)                 # feed the fused template back in place
+        self._graph, self._out = g, (cls, reg, fused)
+
+    def __call__(self, scan):
+        scan = torch.as_tensor(scan, dtype=torch.float32)
+        self._scan.copy_(scan.reshape(self.B, 1, self.N), non_blocking=True)
+        if not self._have_template:                   # first scan of a sequence: eager, template = its own features
+            cls, reg, tmpl, fused = self._step(True)
+            self._store_template(tmpl)
+            self._have_template = True
+        elif not self._use_graph:
+            cls, reg, tmpl, fused = self._step(False)
+            self._store_template(tmpl)
+        else:
+            if self._graph is None:
+                self._capture()                       # warm-up steps read the template, nothing writes it
+            self._graph.replay()
+            cls, reg, fused = self._out
+        self.pred_cls, self.pred_reg, self.feat_fused = cls, reg, fused
+        return cls, reg

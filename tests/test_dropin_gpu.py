@@ -797,3 +797,41 @@ def test_batch_preprocessor_lookahead_chain():
     for got, want in ((got_a, ref[0]), (got_b, ref[1]), (got_d, ref[3]), (got_c, ref[2])):
         for k in keys:
             assert torch.equal(got[k], want[k]), k
+
+
+def test_streaming_detector_graph_replay_equals_eager_steps():
+    """DR-SPAAM streaming mode (reference forward(testing=True, fea_template=...)): the hipGraph replay gives
+    the same numbers as the eager step and as calling the model by hand, across a reset."""
+    from planar_optical_flow_amd import ops
+    from planar_optical_flow_amd.streaming import StreamingDetector
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    torch.manual_seed(11)
+    model = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True).cuda().eval()
+    B = 2
+    scans = torch.from_numpy(synth.make_batch(seed=21, B=B, T=7).scans).cuda()          # [B, 7, 450]
+    eager, graphed = StreamingDetector(model, batch=B, graph=False), StreamingDetector(model, batch=B, graph=True)
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56, padding_val=29.99,
+              area_mode=True)
+    tmpl = None
+    for t in range(7):
+        if t == 4:                                    # a new sequence starts
+            eager.reset(), graphed.reset()
+            tmpl = None
+        ce, re_ = (v.clone() for v in eager(scans[:, t]))
+        cg, rg = graphed(scans[:, t])
+        assert torch.equal(ce, cg) and torch.equal(re_, rg), t
+        assert torch.equal(eager.template, graphed.template) and torch.equal(eager.feat_fused, graphed.feat_fused)
+        with torch.no_grad():
+            x = ops.cutout(scans[:, t:t + 1].contiguous(), ops.phi_table(), **kw)
+            c0, r0, tmpl, f0 = model(x, testing=True, fea_template=tmpl)
+        assert torch.equal(c0, cg) and torch.equal(r0, rg) and torch.equal(f0, graphed.feat_fused), t
+        assert cg.shape == (B, 450, 1) and rg.shape == (B, 450, 2)
+    assert graphed._graph is not None and eager._graph is None
+    addr = graphed.template.data_ptr()
+    graphed.reset()
+    graphed(scans[:, 0]); graphed(scans[:, 1])
+    assert graphed.template.data_ptr() == addr        # the captured graph keeps pointing at the live template
+    # a single sensor passes a 1-D scan
+    one = StreamingDetector(model, batch=1)
+    c1, _ = one(scans[0, 0])
+    assert c1.shape == (1, 450, 1)
