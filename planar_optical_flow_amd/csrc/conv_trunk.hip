@@ -27,6 +27,7 @@ namespace {
 constexpr int kCvWaves = 4;
 constexpr int kCvCC = 4;             // input channels per LDS weight chunk
 constexpr int kCvRows = 3 * kCvCC;   // K rows per chunk (tap-major)
+constexpr long long kCvFillWorkgroups = 256;    // one workgroup = one wave per SIMD on each of the 256 CUs
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
 struct ConvArgs {
@@ -220,11 +221,17 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
         const long long tiles = (ncol + 31) / 32;
         const long long gx = (tiles + kCvWaves - 1) / kCvWaves;
         if (gx > 0x7fffffffLL) return POF_E_SHAPE;
-        if (Co <= 64) {
-            conv3_kernel<2><<<dim3((unsigned)gx, (Co + 63) / 64), 64 * kCvWaves, 0, s>>>(a);
-        } else {
-            conv3_kernel<4><<<dim3((unsigned)gx, (Co + 127) / 128), 64 * kCvWaves, 0, s>>>(a);
-        }
+        // output channels per workgroup: 128 (64 for the narrow layers) when the launch gives every SIMD a wave
+        // (one wave's four independent accumulators already keep its MFMA pipe busy).  A smaller launch
+        // (streaming inference: a few dozen column tiles) leaves SIMDs idle and is bound by one wave's serial
+        // K loop, so it takes narrower channel groups -- more and proportionally shorter workgroups, same
+        // summation order, bit-identical results
+        int ct = Co <= 64 ? 2 : 4;
+        while (ct > 1 && gx * ((Co + 32 * ct - 1) / (32 * ct)) < kCvFillWorkgroups) ct >>= 1;
+        const dim3 grid((unsigned)gx, (Co + 32 * ct - 1) / (32 * ct));
+        if (ct == 1) conv3_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
+        else if (ct == 2) conv3_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
+        else conv3_kernel<4><<<grid, 64 * kCvWaves, 0, s>>>(a);
         POF_CHECK_LAUNCH();
     }
     return POF_OK;

@@ -9,7 +9,7 @@ from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
 
 torch.manual_seed(3)
 model = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True).cuda().eval()
-for B in (1, 8):
+for B in ([int(v) for v in sys.argv[1:]] or [1, 8]):
     scans = torch.from_numpy(synth.make_batch(seed=9, B=B, T=40).scans).cuda()     # [B, 40, 450]
     res = {}
     for graph in (False, True):
@@ -18,8 +18,7 @@ for B in (1, 8):
         for t in range(8):
             cls, reg = det(scans[:, t])
             outs.append((cls.clone(), reg.clone()))
-            torch.cuda.synchronize()
-            print("  B=%d graph=%s step %d done" % (B, graph, t), flush=True)
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for t in range(8, 40):
             det(scans[:, t])
