@@ -111,3 +111,125 @@ def eval_dr_spaam(model, test_loader, cfg=None, output_dir=None, tb_logger=None)
         os.makedirs(output_dir, exist_ok=True)
         np.savez_compressed(os.path.join(output_dir, "flow_eval.npz"), **res)
     return res
+
+
+# ---------------------------------------------------------------------------------------
+# detector loss (reference :31-88) and the legacy box-head evaluations (:436-641)
+# ---------------------------------------------------------------------------------------
+def _batch_get(batch, *names):
+    for n in names:
+        if n in batch:
+            return batch[n]
+    raise KeyError(names[0])
+
+
+def model_fn_obj_det(model, batch, rtn_result=False):
+    """DROW / SpatialDROW training step -> (total_loss, tb_dict, rtn_dict): classification loss over all points
+    (the model's ``cls_loss``; sigmoid + binary form for one-logit models) plus, when the batch has foreground
+    points, the mean Euclidean regression error on them.  Reads ``target_flow_cls`` / ``target_flow_reg`` like the
+    reference, or the ``target_cls`` / ``target_reg`` keys of DROWDataset2 / the device batches."""
+    out = model(_as_dev_f32(batch["input"]))
+    pred_cls, pred_reg = out[0], out[1]
+    tcls = _batch_get(batch, "target_flow_cls", "target_cls")
+    treg = _as_dev_f32(_batch_get(batch, "target_flow_reg", "target_reg"))
+    tcls = (torch.from_numpy(tcls) if isinstance(tcls, np.ndarray) else tcls).to(device=pred_cls.device).long()
+    n_batch, n_pts = tcls.shape[:2]
+    tcls = tcls.reshape(n_batch * n_pts)
+    pred_cls = pred_cls.reshape(n_batch * n_pts, -1)
+    if pred_cls.shape[1] == 1:
+        cls_loss = model.cls_loss(torch.sigmoid(pred_cls.squeeze(-1)), tcls.float(), reduction="mean")
+    else:
+        cls_loss = model.cls_loss(pred_cls, tcls, reduction="mean")
+    total, tb = cls_loss, {"cls_loss": cls_loss.item()}
+    fg = tcls.ne(0)
+    tb["fg_ratio"] = torch.sum(fg).item() / (n_batch * n_pts)
+    pred_reg = pred_reg.reshape(n_batch * n_pts, -1)
+    if tb["fg_ratio"] > 0.0:
+        err = torch.nn.functional.mse_loss(pred_reg[fg], treg.reshape(n_batch * n_pts, -1)[fg], reduction="none")
+        reg_loss = torch.sqrt(torch.sum(err, dim=1)).mean()
+        total = total + reg_loss
+        tb["reg_loss"] = reg_loss.item()
+    rtn = {}
+    if rtn_result:
+        rtn = {"pred_reg": pred_reg.view(n_batch, n_pts, -1), "pred_cls": pred_cls.view(n_batch, n_pts, -1)}
+    return total, tb, rtn
+
+
+def _paired_iou(boxes, targets):
+    """IoU of box i with target i ([B, 5] rows cx, cy, l, w, rot): B groups of one pair, one launch."""
+    b, t = _as_dev_f32(boxes), _as_dev_f32(targets)
+    return ops.rotate_iou(b[:, None, :], t[:, None, :])[:, 0, 0]
+
+
+def _box_eval_batch(model, batch, canonical):
+    """Legacy target layout [cx, cy, l, w, rot / pi]; -> (loss, iou [B], dimension error [B], orientation error [B])."""
+    x, target = _as_dev_f32(batch["input"]), _as_dev_f32(batch["target"])
+    center = _as_dev_f32(batch["det_center"])[:, :2]
+    pred = model(x)
+    loss = model.loss_fn(pred, target[:, 2:])
+    pred, target = pred.clone(), target.clone()
+    pred[:, -1] *= np.pi
+    target[:, -1] *= np.pi
+    if canonical:
+        boxes = torch.cat((torch.zeros_like(center), pred), dim=1)
+    else:
+        boxes = torch.cat((center, pred), dim=1)
+        target[:, :2] += center
+    iou = _paired_iou(boxes, target)
+    return loss, iou, (pred[:, :2] - target[:, 2:4]).abs().sum(dim=1), (pred[:, -1] - target[:, -1]).abs()
+
+
+def model_fn_eval_box_reg(model, eval_loader):
+    """-> (mean loss, mean dimension error, mean orientation error, mean IoU), per-batch means averaged (:520-559).
+    The IoU of prediction i with target i comes from one paired launch per batch instead of the diagonal of the
+    reference's full B x B matrix."""
+    model.eval()
+    loss_sum, dim, ori, iou = 0.0, [], [], []
+    with torch.no_grad():
+        for batch in eval_loader:
+            loss, i, d, o = _box_eval_batch(model, batch, canonical=True)
+            loss_sum += loss
+            iou.append(i.mean().item()), dim.append(d.mean().item()), ori.append(o.mean().item())
+    return loss_sum / len(eval_loader), np.mean(dim), np.mean(ori), np.mean(iou)
+
+
+def eval_Bb_regression(model, test_loader, cfg=None, output_dir=None, tb_logger=None):
+    """Per-sample box-head evaluation in the scanner frame (:436-518): the reference walks a batch-size-1 loader and
+    plots a window of frames; here every sample of every batch is scored (IoU with the box placed at its detection
+    centre, |dl| + |dw|, |d rot|) and the arrays are returned (and saved under output_dir) instead of plotted."""
+    import os
+    model.eval()
+    loss_sum, dim, ori, iou = 0.0, [], [], []
+    with torch.no_grad():
+        for batch in test_loader:
+            loss, i, d, o = _box_eval_batch(model, batch, canonical=False)
+            loss_sum += float(loss)
+            iou.append(i.cpu().numpy()), dim.append(d.cpu().numpy()), ori.append(o.cpu().numpy())
+    res = {"eval_loss": loss_sum / max(len(test_loader), 1), "iou": np.concatenate(iou),
+           "dimension_err": np.concatenate(dim), "orientation_err": np.concatenate(ori)}
+    print("Eval loss: ", res["eval_loss"])
+    print("avg dimension error: {:0.3f} [m]".format(res["dimension_err"].mean()))
+    print("avg orientation error: {:0.3f} [rad]".format(res["orientation_err"].mean()))
+    print("avg IOU: {:0.3f}".format(res["iou"].mean()))
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(output_dir, "box_eval.npz"), **res)
+    return res
+
+
+def eval_BB_reg_baseline(dataset):
+    """Baseline of the box head (:561-641): predict the data set's mean length / width at rot = pi / 2 around every
+    detection centre and score it against the annotation -- all samples in one paired IoU launch.
+    dataset: ``.targets`` rows [cx, cy, l, w, rot], ``.dets_center``.  -> dict(iou, dimension_err, orientation_err)."""
+    targets = np.asarray(dataset.targets, dtype=np.float64)[:, :5]
+    centers = np.asarray(dataset.dets_center, dtype=np.float64)[:, :2]
+    pred = np.array([targets[:, 2].mean(), targets[:, 3].mean(), 0.5 * np.pi])
+    boxes = np.hstack((centers, np.broadcast_to(pred, (len(centers), 3))))
+    res = {"iou": _paired_iou(boxes, targets).cpu().numpy(),
+           "dimension_err": np.abs(pred[:2] - targets[:, 2:4]).sum(axis=1),
+           "orientation_err": np.abs(pred[2] - targets[:, 4])}
+    print("Eval loss: ", res["dimension_err"].mean() + res["orientation_err"].mean())
+    print("avg dimension error: {:0.3f} [m]".format(res["dimension_err"].mean()))
+    print("avg orientation error: {:0.3f} [rad]".format(res["orientation_err"].mean()))
+    print("avg IOU: {:0.3f}".format(res["iou"].mean()))
+    return res

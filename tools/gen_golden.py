@@ -521,6 +521,25 @@ def main():
     with torch.no_grad():
         dc, dr_ = dref(xd)
     gm["drow_x"], gm["drow_cls"], gm["drow_reg"] = xd.numpy(), dc.numpy(), dr_.numpy()
+    # the detector's loss adapter on both heads (one-logit sigmoid / BCE, four-class cross entropy)
+    torch.manual_seed(3)                          # a fresh copy: the train-mode forward above moved the BatchNorm statistics
+    mref = spaam.SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+    mref.eval()
+    rs = np.random.default_rng(17)
+    tc1 = (rs.uniform(size=(2, 30)) < 0.3).astype(np.int64)
+    tr1 = rs.normal(size=(2, 30, 2)).astype(np.float32)
+    with torch.no_grad():
+        l1, tb1, _ = eval_utils.model_fn_obj_det(mref, {"input": xin.numpy(), "target_flow_cls": tc1, "target_flow_reg": tr1})
+    gm["objdet1_cls"], gm["objdet1_reg"] = tc1, tr1
+    gm["objdet1_out"] = np.array([float(l1), tb1["cls_loss"], tb1["fg_ratio"], tb1["reg_loss"]])
+    tc4 = rs.integers(0, 4, (2, 25)).astype(np.int64)
+    tr4 = rs.normal(size=(2, 25, 2)).astype(np.float32)
+    with torch.no_grad():
+        l4, tb4, _ = eval_utils.model_fn_obj_det(dref, {"input": xd.numpy(), "target_flow_cls": tc4, "target_flow_reg": tr4})
+        l0, tb0, _ = eval_utils.model_fn_obj_det(dref, {"input": xd.numpy(), "target_flow_cls": tc4 * 0, "target_flow_reg": tr4})
+    gm["objdet4_cls"], gm["objdet4_reg"] = tc4, tr4
+    gm["objdet4_out"] = np.array([float(l4), tb4["cls_loss"], tb4["fg_ratio"], tb4["reg_loss"]])
+    gm["objdet0_out"] = np.array([float(l0), tb0["cls_loss"], tb0["fg_ratio"]])        # no foreground: no reg term
     np.savez_compressed(os.path.join(OUT, "dr_spaam_model.npz"), **gm)
 
     # ---------------- N2: Prototype flow network (weights rebuilt from the seed) ----------------
