@@ -233,3 +233,33 @@ def eval_BB_reg_baseline(dataset):
     print("avg orientation error: {:0.3f} [rad]".format(res["orientation_err"].mean()))
     print("avg IOU: {:0.3f}".format(res["iou"].mean()))
     return res
+
+
+def eval(model, test_loader, cfg=None, output_dir=None, tb_logger=None):     # noqa: A001 -- the reference's name
+    """Flow evaluation of the scan-pair (Prototype) network (reference :157-219): predictions shorter than 1e-6 are
+    zeroed, the per-sample EPE comes from ``loss_fn_eval`` (HIP), the loss is the mean of the per-batch means.  The
+    video rendering is visualisation and not rebuilt: with ``output_dir`` the arrays go to ``flow_eval.npz``.
+    -> dict(eval_loss, epe [S], scans [S, N, C], pred_flow, target_flow)."""
+    import os
+    model.eval()
+    total, scans, preds, targets, epes = 0.0, [], [], [], []
+    with torch.no_grad():
+        for batch in test_loader:
+            pair = batch["scan_pair"]
+            scan1, scan2 = _as_dev_f32(pair[:, 0]), _as_dev_f32(pair[:, 1])
+            target = _as_dev_f32(batch["flow_target_flow"])
+            pred = model(scan1, scan2).float().contiguous()
+            pred[torch.norm(pred, dim=-1) <= 1e-6] = 0.0
+            epe, _ = loss_fn_eval(pred, target)
+            total += epe.mean().item()
+            scans.append(scan1.cpu().numpy()), preds.append(pred.cpu().numpy())
+            targets.append(target.cpu().numpy()), epes.append(epe.cpu().numpy())
+    res = {"eval_loss": total / max(len(test_loader), 1), "epe": np.concatenate(epes), "scans": np.concatenate(scans),
+           "pred_flow": np.concatenate(preds), "target_flow": np.concatenate(targets)}
+    print("Eval loss: ", res["eval_loss"])
+    if tb_logger is not None:
+        tb_logger.add_scalar("eval_loss", res["eval_loss"], 0)
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(output_dir, "flow_eval.npz"), **res)
+    return res

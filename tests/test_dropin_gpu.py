@@ -922,3 +922,24 @@ def test_legacy_box_head_evaluations():
     full = R.rotate_iou(np.hstack((DS.dets_center, np.tile(pred, (40, 1)))).astype(np.float32), DS.targets.astype(np.float32))
     np.testing.assert_allclose(base["iou"], np.diag(full), atol=2e-5)
     np.testing.assert_allclose(base["orientation_err"], np.abs(pred[2] - DS.targets[:, 4]))
+
+
+def test_prototype_eval_loop(tmp_path):
+    """eval_utils.eval (the scan-pair network's evaluation): per-sample EPE equals the oracle's flow error on the
+    zero-thresholded predictions; arrays are written instead of the reference's video."""
+    from planar_optical_flow_amd.src.depracted.model.prototype import Prototype
+    from planar_optical_flow_amd.src.utils import eval_utils as eu
+    torch.manual_seed(5)
+    model = Prototype(in_channel=1, max_displacement=5).cuda()
+    rng = np.random.default_rng(4)
+    loader = [{"scan_pair": rng.normal(size=(n, 2, 450, 1)).astype(np.float32),
+               "flow_target_flow": rng.normal(size=(n, 450, 2)).astype(np.float32)} for n in (3, 2)]
+    res = eu.eval(model, loader, output_dir=str(tmp_path))
+    assert res["epe"].shape == (5,) and res["pred_flow"].shape == (5, 450, 2) and (tmp_path / "flow_eval.npz").exists()
+    want = np.linalg.norm(res["pred_flow"].astype(np.float64) - res["target_flow"], axis=-1).mean(axis=1)
+    np.testing.assert_allclose(res["epe"], want, rtol=1e-5)
+    np.testing.assert_allclose(res["eval_loss"], (want[:3].mean() + want[3:].mean()) / 2, rtol=1e-5)
+    model.eval()
+    with torch.no_grad():
+        direct = model(torch.from_numpy(loader[1]["scan_pair"][:, 0]).cuda(), torch.from_numpy(loader[1]["scan_pair"][:, 1]).cuda())
+    np.testing.assert_allclose(direct.float().cpu().numpy(), res["pred_flow"][3:], rtol=1e-4, atol=1e-4)   # MIOpen convs
