@@ -263,3 +263,52 @@ def eval(model, test_loader, cfg=None, output_dir=None, tb_logger=None):     # n
         os.makedirs(output_dir, exist_ok=True)
         np.savez_compressed(os.path.join(output_dir, "flow_eval.npz"), **res)
     return res
+
+
+def eval_person_flow(model, test_loader, cfg=None, output_dir=None, tb_logger=None):
+    """Detection + flow evaluation of a (pred_cls, pred_reg, pred_flow) network (reference :320-434).  The reference
+    runs one sample per batch: NMS of the predicted centres on the host, EPE / AAE, flows back to the scanner
+    frame, then a video.  Here a batch of any size takes one ``pof_nms`` launch for all its scans, one flow-error
+    launch and one rotation launch per tensor; the arrays are returned (and written to ``person_flow_eval.npz``
+    under output_dir) instead of rendered.  The model is called as ``model(input)``, or ``model(input, cur_scan)``
+    for ``FlowDROW_pretrained``.
+    -> dict(eval_loss, epe, aae, pred_flow, target_flow, scans, dets_xy (list), dets_cls (list), instance_masks)."""
+    import inspect
+    import os
+    model.eval()
+    takes_scan = len(inspect.signature(model.forward).parameters) > 1 and "cur_scan" in inspect.signature(model.forward).parameters
+    tab = None
+    total, out = 0.0, {k: [] for k in ("epe", "aae", "pred_flow", "target_flow", "scans", "instance_masks")}
+    dets_xy, dets_cls = [], []
+    with torch.no_grad():
+        for batch in test_loader:
+            scans = batch["scans"]
+            scan = _as_dev_f32(scans[:, -2] if not takes_scan else scans[:, -1])
+            x, target = _as_dev_f32(batch["input"]), _as_dev_f32(batch["target_flow"])
+            pred_cls, pred_reg, pred_flow = model(x, scan) if takes_scan else model(x)
+            pred_flow = pred_flow.float().contiguous()
+            if tab is None:
+                tab = ops.phi_table(num_pts=scan.shape[-1], device=scan.device)
+            conf = torch.sigmoid(pred_cls[..., 0]).double().contiguous()
+            xy, dc, num, inst = ops.nms_predicted_center(scan, tab, conf, pred_reg.double().contiguous(), 0.5)
+            for b, m in enumerate(num.cpu().numpy()):
+                dets_xy.append(xy[b, :m].cpu().numpy())
+                dets_cls.append(dc[b, :m].cpu().numpy().reshape(-1, 1))
+            e, a = loss_fn_eval(pred_flow, target)
+            total += e.mean().item()
+            out["epe"].append(e.cpu().numpy()), out["aae"].append(a.cpu().numpy())
+            out["pred_flow"].append(ops.rotate_flow(pred_flow, tab, to_canonical=False).cpu().numpy())
+            out["target_flow"].append(ops.rotate_flow(target, tab, to_canonical=False).cpu().numpy())
+            out["scans"].append(scan.cpu().numpy()), out["instance_masks"].append(inst.cpu().numpy())
+    res = {k: np.concatenate(v) for k, v in out.items()}
+    res.update(eval_loss=total / max(len(test_loader), 1), dets_xy=dets_xy, dets_cls=dets_cls)
+    print("Eval loss: ", res["eval_loss"])
+    if tb_logger is not None:
+        tb_logger.add_scalar("eval_loss", res["eval_loss"], 0)
+    if output_dir is not None:
+        os.makedirs(output_dir, exist_ok=True)
+        np.savez_compressed(os.path.join(output_dir, "person_flow_eval.npz"),
+                            **{k: v for k, v in res.items() if k not in ("dets_xy", "dets_cls")},
+                            dets_count=np.array([len(d) for d in dets_xy]),
+                            dets_xy=np.concatenate(dets_xy) if dets_xy else np.zeros((0, 2)))
+    return res

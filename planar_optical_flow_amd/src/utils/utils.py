@@ -284,6 +284,24 @@ def nms_predicted_center(scan_grid, phi_grid, pred_cls, pred_reg, min_dist=0.5):
     return xy[0, :m].cpu().numpy(), dc[0, :m].cpu().numpy().reshape(-1, 1).astype(pc.dtype), inst[0].cpu().numpy()
 
 
+def flow_to_hsv(flow):
+    """:574-584.  Flow vectors [..., 2] -> RGB colours [..., 3] (float64): hue from the direction, saturation from
+    min(|flow|, 0.1) / 0.1, value 1.  The polar conversion is the HIP ``xy_to_rphi``; the HSV -> RGB step repeats
+    ``colorsys.hsv_to_rgb``'s arithmetic for all vectors at once instead of one Python call per point."""
+    fl = flow.detach().cpu().numpy() if _is_t(flow) else np.asarray(flow)
+    r, phi = xy_to_rphi(np.ascontiguousarray(fl[..., 0], dtype=np.float64), np.ascontiguousarray(fl[..., 1], dtype=np.float64))
+    h = (phi + 2.0 * np.pi) / np.pi / 2
+    sat = np.minimum(r, 0.1) / 0.1
+    v = np.ones_like(h)
+    sector = (h * 6.0).astype(np.int64)             # int(): truncation; h > 0 here
+    f = h * 6.0 - sector
+    p, q, t = v * (1.0 - sat), v * (1.0 - sat * f), v * (1.0 - sat * (1.0 - f))
+    sector = sector % 6
+    table = np.stack([np.stack(c, axis=-1) for c in ((v, t, p), (q, v, p), (p, v, t), (p, q, v), (t, p, v), (v, p, q))])
+    rgb = np.take_along_axis(table, sector[None, ..., None], axis=0)[0]
+    return np.where((sat == 0.0)[..., None], v[..., None], rgb)
+
+
 def data_augmentation(sample_dict):
     """:129-144.  Host-side random left-right flip (uses the global NumPy RNG like
     the reference)."""

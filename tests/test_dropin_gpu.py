@@ -943,3 +943,51 @@ def test_prototype_eval_loop(tmp_path):
     with torch.no_grad():
         direct = model(torch.from_numpy(loader[1]["scan_pair"][:, 0]).cuda(), torch.from_numpy(loader[1]["scan_pair"][:, 1]).cuda())
     np.testing.assert_allclose(direct.float().cpu().numpy(), res["pred_flow"][3:], rtol=1e-4, atol=1e-4)   # MIOpen convs
+
+
+def test_flow_to_hsv_equals_reference(golden):
+    import src.utils.utils as u
+    g = golden("flow_hsv")
+    rgb = u.flow_to_hsv(g["flow"])
+    assert rgb.shape == g["rgb"].shape == (len(g["flow"]), 3)
+    np.testing.assert_allclose(rgb, g["rgb"], rtol=0, atol=1e-12)
+    assert np.array_equal(u.flow_to_hsv(np.zeros((4, 2))), np.ones((4, 3)))          # zero flow: white
+    assert u.flow_to_hsv(torch.from_numpy(g["flow"]).cuda().reshape(2, -1, 2)).shape == (2, len(g["flow"]) // 2, 3)
+
+
+def test_eval_person_flow_loop(tmp_path):
+    """eval_person_flow: per-sample detections equal the (pinned) single-scan nms_predicted_center, flow errors equal
+    loss_fn_eval, flows come back in the scanner frame."""
+    import src.utils.utils as u
+    from planar_optical_flow_amd.src.utils import eval_utils as eu
+
+    class Net(torch.nn.Module):
+        def forward(self, x):                         # x [B, N, T, P] cutouts -> fixed functions of the cutout
+            m = x.mean(dim=(2, 3))
+            cls = (3.0 * torch.sin(7.0 * m) - 1.0).unsqueeze(-1)
+            reg = torch.stack((0.3 * torch.cos(5.0 * m), 0.3 * torch.sin(3.0 * m)), dim=-1)
+            return cls, reg, torch.stack((0.1 * m, -0.05 * m), dim=-1)
+    sb = synth.make_batch(seed=31, B=5, T=3)
+    rng = np.random.default_rng(1)
+    loader = []
+    for lo, hi in ((0, 3), (3, 5)):
+        loader.append({"scans": sb.scans[lo:hi], "input": rng.normal(size=(hi - lo, 450, 3, 8)).astype(np.float32),
+                       "target_flow": rng.normal(size=(hi - lo, 450, 2)).astype(np.float32) * 0.1})
+    model = Net().cuda()
+    res = eu.eval_person_flow(model, loader, output_dir=str(tmp_path))
+    assert res["epe"].shape == (5,) and len(res["dets_xy"]) == 5 and (tmp_path / "person_flow_eval.npz").exists()
+    phi = u.get_laser_phi()
+    k = 0
+    for b in loader:
+        with torch.no_grad():
+            cls, reg, flow = model(torch.from_numpy(b["input"]).cuda())
+        e, a = eu.loss_fn_eval(flow, b["target_flow"])
+        for i in range(len(b["scans"])):
+            xy, dc, inst = u.nms_predicted_center(b["scans"][i, -2], phi, torch.sigmoid(cls[i]).cpu().numpy().astype(np.float64),
+                                                  reg[i].cpu().numpy().astype(np.float64))
+            assert np.array_equal(res["dets_xy"][k], xy) and np.array_equal(res["dets_cls"][k], dc)
+            assert np.array_equal(res["instance_masks"][k], inst)
+            assert res["epe"][k] == e[i].item() and res["aae"][k] == a[i].item()
+            np.testing.assert_allclose(res["pred_flow"][k], u.canonical_to_global_flow(flow[i].cpu().numpy(), phi), atol=1e-6)
+            k += 1
+    assert sum(len(d) for d in res["dets_xy"]) > 0

@@ -484,6 +484,12 @@ def main():
         ga["ft%d_features" % b] = np.array(dsa.compute_feature(dsa.scans_data[b], b), dtype=np.float64).reshape(-1, 15)
     np.savez_compressed(os.path.join(OUT, "adaboost.npz"), **ga)
 
+    # ---------------- flow_to_hsv (colour coding of flow vectors, used by the evaluation loops) -------
+    rh = np.random.default_rng(606)
+    fl = np.concatenate([rh.normal(size=(300, 2)) * 0.05, rh.normal(size=(100, 2)), np.zeros((3, 2)),
+                         np.array([[0.1, 0.0], [0.0, 0.1], [-0.1, 0.0], [0.0, -0.1], [-1e-9, -0.0]])])
+    np.savez_compressed(os.path.join(OUT, "flow_hsv.npz"), flow=fl, rgb=u.flow_to_hsv(fl))
+
     # ---------------- N4: scans_to_polar_grid -------------------------------------------------
     gp = {}
     sbp = synth.make_batch(seed=81, B=2, T=5)
