@@ -26,9 +26,11 @@ class StreamingDetector:
     buffers -- valid until the next call; ``.clone()`` to keep them.  ``feat_fused`` (the window similarities
     of the last step, input of the flow head) and ``template`` are attributes.  ``reset()`` forgets the
     template, as at the start of a sequence.  ``graph=False`` runs the same step eagerly (reference for
-    tests and timing)."""
+    tests and timing).  With ``nms_min_dist`` (one-logit models) the greedy centre NMS of
+    ``utils.nms_predicted_center`` runs inside the same step and ``detections()`` returns its result."""
 
-    def __init__(self, model, num_pts=450, batch=1, angle_inc=None, cutout_kwargs=None, graph=True, device="cuda"):
+    def __init__(self, model, num_pts=450, batch=1, angle_inc=None, cutout_kwargs=None, graph=True, device="cuda",
+                 nms_min_dist=None):
         if not torch.cuda.is_available():
             raise RuntimeError("StreamingDetector needs the GPU (no CPU path)")
         self.model = model.to(device).eval()
@@ -40,6 +42,8 @@ class StreamingDetector:
             else ops.phi_table(angle_inc, self.N, device=dev)
         self._scan = torch.zeros((self.B, 1, self.N), dtype=torch.float32, device=dev)
         self._use_graph = bool(graph)
+        self._nms = None if nms_min_dist is None else float(nms_min_dist)
+        self._dets = None
         self._graph = None
         self.template = None            # fixed buffer once the first scan has been seen
         self._have_template = False
@@ -53,6 +57,11 @@ class StreamingDetector:
         x = ops.cutout(self._scan, self.tab, **self.kw)
         with torch.no_grad():
             cls, reg, tmpl, fused = self.model(x, testing=True, fea_template=None if first else self.template)
+            if self._nms is not None:
+                if cls.shape[-1] != 1:
+                    raise ValueError("nms_min_dist needs a one-logit (pedestrian_only) model")
+                conf = torch.sigmoid(cls[..., 0]).double().contiguous()
+                self._dets = ops.nms_predicted_center(self._scan[:, 0], self.tab, conf, reg.double().contiguous(), self._nms)
         return cls, reg, tmpl, fused
 
     def _store_template(self, tmpl):
@@ -72,7 +81,7 @@ class StreamingDetector:
         with torch.cuda.graph(g):
             cls, reg, tmpl, fused = self._step(False)
             self.template.copy_(tmpl)                 # feed the fused template back in place
-        self._graph, self._out = g, (cls, reg, fused)
+        self._graph, self._out, self._graph_dets = g, (cls, reg, fused), self._dets
 
     def __call__(self, scan):
         scan = torch.as_tensor(scan, dtype=torch.float32)
@@ -89,5 +98,15 @@ class StreamingDetector:
                 self._capture()                       # warm-up steps read the template, nothing writes it
             self._graph.replay()
             cls, reg, fused = self._out
+            self._dets = self._graph_dets
         self.pred_cls, self.pred_reg, self.feat_fused = cls, reg, fused
         return cls, reg
+
+    def detections(self):
+        """-> list (one entry per sensor) of (xy [M, 2], confidence [M]) NumPy arrays and the instance masks [B, N]
+        of the last step (needs ``nms_min_dist``).  Reads the counts back, i.e. synchronises."""
+        if self._dets is None:
+            raise RuntimeError("construct the detector with nms_min_dist and feed it a scan first")
+        xy, conf, num, inst = self._dets
+        counts = num.cpu().numpy()
+        return [(xy[b, :m].cpu().numpy(), conf[b, :m].cpu().numpy()) for b, m in enumerate(counts)], inst.cpu().numpy()

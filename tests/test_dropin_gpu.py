@@ -835,6 +835,19 @@ def test_streaming_detector_graph_replay_equals_eager_steps():
     one = StreamingDetector(model, batch=1)
     c1, _ = one(scans[0, 0])
     assert c1.shape == (1, 450, 1)
+    # detections inside the replayed step equal the stand-alone NMS on the step's outputs
+    import src.utils.utils as u
+    dn = StreamingDetector(model, batch=B, nms_min_dist=0.5)
+    with pytest.raises(RuntimeError):
+        dn.detections()
+    for t in range(4):
+        cls, reg = dn(scans[:, t])
+        dets, inst = dn.detections()
+        for b in range(B):
+            xy, dc, im = u.nms_predicted_center(scans[b, t].cpu().numpy(), u.get_laser_phi(),
+                                                torch.sigmoid(cls[b]).double().cpu().numpy(), reg[b].double().cpu().numpy())
+            assert np.array_equal(dets[b][0], xy) and np.array_equal(dets[b][1], dc[:, 0]) and np.array_equal(inst[b], im)
+    assert dn._graph is not None
 
 
 def test_model_fn_obj_det_equals_reference(golden):
