@@ -6,9 +6,8 @@ blocks, fused with the running template by the attention gate and classified; th
 back on the next call: ~30 kernel launches per scan.  ``StreamingDetector`` keeps the scan, the template and
 the outputs in fixed device buffers, captures the steady-state step once and replays it, so the host thread
 issues one graph launch per scan instead of thirty kernel launches.  Measured on MI355X
-(tools/bench_stream.py): 0.60 ms per scan at one sensor, 2.11 ms at eight -- the same as the eager step, whose
-launches already run ahead of the GPU; the step is bound by the per-layer latency of the small grids, and the
-replay's gain is the freed host thread, not GPU time.  Outputs are bit-identical to the eager step.
+(tools/bench_stream.py): the replay takes 0.57-0.60 ms per scan at one sensor and 2.11 ms at eight; the eager
+step is host-bound at one sensor and took 0.60 to 2.35 ms on different boxes.  Outputs are bit-identical to the eager step.
 """
 import torch
 
