@@ -4,7 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from planar_optical_flow_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-SA, SC = B * 450 * 5, B * 450
+STREAM = len(sys.argv) > 2 and sys.argv[2].startswith("stream")
+GRAPH = len(sys.argv) > 2 and sys.argv[2] == "stream"      # streaming step: one scan per window, timed inside a graph
+SA, SC = (B * 450 if STREAM else B * 450 * 5), B * 450
 layers = [(SA, 1, 64, 56, 0), (SA, 64, 64, 56, 0), (SA, 64, 128, 56, 1), (SA, 128, 128, 28, 0), (SA, 128, 128, 28, 0),
           (SA, 128, 256, 28, 1), (SC, 256, 256, 14, 0), (SC, 256, 256, 14, 0), (SC, 256, 512, 14, 1),
           (SC, 512, 256, 7, 0), (SC, 256, 128, 7, 0)]
@@ -17,12 +19,21 @@ for (S, Ci, Co, L, pool) in layers:
     for _ in range(2): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / 5
+    if GRAPH:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(20): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
+        g.replay(); torch.cuda.synchronize()
+        e0.record(); g.replay(); e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+    else:
+        e0.record()
+        for _ in range(5): ops.conv3_bn_lrelu(x, wt, sc, sh, pool=bool(pool), out=out)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
     fl = 2.0 * S * L * Co * Ci * 3
     byt = 4.0 * S * (Ci * L + Co * (L // 2 if pool else L))
     tot_ms += ms; tot_fl += fl
-    print("S=%6d Ci=%3d Co=%3d L=%2d pool=%d: %7.3f ms  %6.1f TFLOP/s  %6.0f GB/s" % (S, Ci, Co, L, pool, ms, fl / ms / 1e9, byt / ms / 1e6), flush=True)
+    mfma_us = -(-S * L // 32) * -(-Co // 32) * (Ci * 3 + 1) // 2 * 0.030 / 1024      # all 1024 SIMDs busy, 30 ns per 32x32x2
+    print("S=%6d Ci=%3d Co=%3d L=%2d pool=%d: %7.3f ms  %6.1f TFLOP/s  %6.0f GB/s  (MFMA-issue bound %.1f us)" % (S, Ci, Co, L, pool, ms, fl / ms / 1e9, byt / ms / 1e6, mfma_us), flush=True)
 print("trunk total %.2f ms  %.1f TFLOP/s" % (tot_ms, tot_fl / tot_ms / 1e9))
