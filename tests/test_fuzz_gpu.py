@@ -14,6 +14,9 @@ from planar_optical_flow_amd import synth  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+# POF_FUZZ_SCALE=k multiplies the number of seeds of every sweep (soak runs; the default suite uses 1)
+_SCALE = max(1, int(os.environ.get("POF_FUZZ_SCALE", "1")))
+
 
 @pytest.fixture(scope="module")
 def ops():
@@ -25,7 +28,7 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 * _SCALE))
 def test_fuzz_cutout_bit_exact(ops, seed):
     rng = np.random.default_rng(1000 + seed)
     N = int(rng.choice([33, 64, 90, 180, 255, 450, 720]))
@@ -50,7 +53,7 @@ def test_fuzz_cutout_bit_exact(ops, seed):
     assert (fast - got).abs().max().item() <= 2e-5 * max(1.0, 1.0 / kw["window_depth"]) * (30.0 if not kw["centered"] else 1.0)
 
 
-@pytest.mark.parametrize("seed", range(16))
+@pytest.mark.parametrize("seed", range(16 * _SCALE))
 def test_fuzz_scan_preprocess(ops, seed):
     rng = np.random.default_rng(3000 + seed)
     N = int(rng.choice([31, 90, 225, 450, 451, 900]))
@@ -84,7 +87,7 @@ def test_fuzz_scan_preprocess(ops, seed):
         assert np.array_equal(out["dyn_mask"][b].cpu().numpy().astype(np.float64), dyn), (seed, b)
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(12 * _SCALE))
 def test_fuzz_attention_and_correlation(ops, seed):
     rng = np.random.default_rng(5000 + seed)
     B, N = int(rng.integers(1, 4)), int(rng.choice([3, 17, 40, 64, 100, 257]))
@@ -129,7 +132,7 @@ def test_pedestrian_only_batch_keeps_all_classes_in_the_mask(ops):
     assert n_other > 0
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(10 * _SCALE))
 def test_fuzz_nms_and_polar_grid(ops, seed):
     rng = np.random.default_rng(6000 + seed)
     N = int(rng.choice([17, 64, 100, 450, 451, 700]))
@@ -160,7 +163,7 @@ def test_fuzz_nms_and_polar_grid(ops, seed):
         assert np.array_equal(got[b], R.polar_grid(sbp.scans[b], **kw)), (seed, kw)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * _SCALE))
 def test_fuzz_segments_iou_conv(ops, seed):
     rng = np.random.default_rng(9000 + seed)
     # A13: cut indices bit-exact, simple features tight, fits on well conditioned segments
@@ -214,7 +217,7 @@ def test_fuzz_segments_iou_conv(ops, seed):
     assert torch.equal(got, want), (S, Ci, Co, L, pool)
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(8 * _SCALE))
 def test_fuzz_standalone_geometry_and_store(ops, seed):
     """A3 / A5 / A12 stand-alone entry points and the N1 store kernels on random shapes."""
     rng = np.random.default_rng(11000 + seed)
@@ -242,7 +245,10 @@ def test_fuzz_standalone_geometry_and_store(ops, seed):
     np.testing.assert_allclose(dy.cpu().numpy(), wy, rtol=0, atol=1e-12)
     rr, pp = ops.canonical_to_det(dev(r), tab, dx, dy)
     wr, wp = R.canonical_to_det(r.astype(np.float64), phi[None], wx, wy)
-    np.testing.assert_allclose(rr.cpu().numpy(), wr, rtol=1e-12, atol=1e-12)
+    # r = (r + dy) / cos(atan2(dx, r + dy)) is ill-conditioned where the detection is at right angles to the ray:
+    # a last-bit difference of atan2 / cos is amplified by 1 / |cos|, and so is the bound (found by the 64x soak)
+    cond = 1.0 / np.maximum(np.abs(np.cos(np.arctan2(wx, r.astype(np.float64) + wy))), 1e-9)
+    assert np.all(np.abs(rr.cpu().numpy() - wr) <= 1e-12 * (1.0 + np.abs(wr)) * np.maximum(cond, 1.0))
     np.testing.assert_allclose(pp.cpu().numpy(), wp, rtol=0, atol=1e-12)
     # A12
     pred = rng.normal(0, 1, (B, N, 2)).astype(np.float32)
