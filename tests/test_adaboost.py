@@ -9,6 +9,7 @@ import pytest
 from oracle import ref_numpy as R
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "adaboost.npz")
+_SCALE = max(1, int(os.environ.get("POF_FUZZ_SCALE", "1")))      # soak runs: more random tables
 
 # reference feature column -> column of segment_features (oracle and pof_segment_features); the reference's
 # median deviation (2), succeeding jump (4) and mean speed (13) are defects and not restated
@@ -113,7 +114,7 @@ def test_stump_search_fuzz_against_oracle(detector):
     largest sample count and one-dimensional tables: per-dimension counts and thresholds equal the oracle's."""
     import torch
     rng = np.random.default_rng(99)
-    for trial in range(14):
+    for trial in range(14 * _SCALE):
         n = int(rng.choice([2, 3, 17, 64, 200, 257, 1000, 2048]))
         D = int(rng.integers(1, 20))
         X = rng.normal(size=(n, D)) * 3
@@ -141,7 +142,7 @@ def test_stump_search_fuzz_against_oracle(detector):
 @pytest.mark.gpu
 def test_adaboost_fuzz_against_oracle(detector):
     rng = np.random.default_rng(7)
-    for trial in range(3):
+    for trial in range(3 * _SCALE):
         N, D = int(rng.integers(150, 900)), int(rng.integers(2, 13))
         X = rng.normal(size=(N, D))
         Y = np.where(X @ rng.normal(size=D) + 0.7 * rng.normal(size=N) > 0, 1.0, -1.0)
