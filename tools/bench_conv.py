@@ -10,6 +10,9 @@ SA, SC = (B * 450 if STREAM else B * 450 * 5), B * 450
 layers = [(SA, 1, 64, 56, 0), (SA, 64, 64, 56, 0), (SA, 64, 128, 56, 1), (SA, 128, 128, 28, 0), (SA, 128, 128, 28, 0),
           (SA, 128, 256, 28, 1), (SC, 256, 256, 14, 0), (SC, 256, 256, 14, 0), (SC, 256, 512, 14, 1),
           (SC, 512, 256, 7, 0), (SC, 256, 128, 7, 0)]
+if len(sys.argv) > 3 and sys.argv[3] == "sweep":      # time vs Ci at fixed output shape: slope = per-chunk cost, intercept = fixed cost
+    layers = [(SC, Ci, 256, 7, 0) for Ci in (64, 128, 256, 512, 1024)] + [(SC, Ci, 64, 56, 0) for Ci in (16, 64, 256, 1024)] \
+        + [(SC, Ci, 128, 28, 0) for Ci in (32, 128, 512)]
 tot_ms = tot_fl = 0.0
 for (S, Ci, Co, L, pool) in layers:
     x = torch.randn((S, Ci, L), device="cuda")
