@@ -24,23 +24,22 @@ __global__ void k(float *out, float a, float b, int n)
 }
 
 template <int NACC>
-void run(float *d, int waves_per_simd)
+void run(float *d, int waves_per_simd, int blocks = 256, int n = 256)
 {
-    const int n = 256;
-    k<NACC><<<256, 256 * waves_per_simd>>>(d, 1.0f, 0.5f, n);
+    k<NACC><<<blocks, 256 * waves_per_simd>>>(d, 1.0f, 0.5f, n);
     hipDeviceSynchronize();
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    k<NACC><<<256, 256 * waves_per_simd>>>(d, 1.0f, 0.5f, n);
+    k<NACC><<<blocks, 256 * waves_per_simd>>>(d, 1.0f, 0.5f, n);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms; hipEventElapsedTime(&ms, e0, e1);
     float cyc;
-    hipMemcpy(&cyc, d + 256 * 256 * waves_per_simd, sizeof(float), hipMemcpyDeviceToHost);
+    hipMemcpy(&cyc, d + blocks * 256 * waves_per_simd, sizeof(float), hipMemcpyDeviceToHost);
     const double mf = (double)n * 8 * NACC;
-    printf("accumulators %d, waves/SIMD %d: %.1f memtime ticks per MFMA per wave, %.2f ns per MFMA (kernel %.1f us)\n",
-           NACC, waves_per_simd, cyc / mf, ms * 1e6 / mf, ms * 1e3);
+    printf("accumulators %d, waves/SIMD %d, %3d workgroups, %4d MFMAs per wave: %.1f memtime ticks per MFMA, %.2f ns per MFMA (kernel %.1f us)\n",
+           NACC, waves_per_simd, blocks, n * 8 * NACC, cyc / mf, ms * 1e6 / mf, ms * 1e3);
 }
 
 int main()
@@ -49,5 +48,7 @@ int main()
     hipMalloc(&d, (256 * 1024 + 8) * sizeof(float));
     run<1>(d, 1); run<2>(d, 1); run<4>(d, 1);
     run<1>(d, 2); run<1>(d, 4);
+    // the shape of a small conv launch: a few hundred MFMAs per wave, fewer workgroups than CUs, launched cold
+    run<1>(d, 1, 100, 48); run<1>(d, 1, 200, 96); run<1>(d, 1, 200, 24);
     return 0;
 }
