@@ -291,6 +291,25 @@ int pof_segment_features(const float *ranges, const double *tab, int B, int N, d
                          int max_seg, int32_t *seg_id, int32_t *num_seg, double *feat,
                          pof_stream_t stream);
 
+/* The reference's own feature rows, Dataset.scan_to_segments + compute_feature
+ *   src/depracted/model/adaboost_person_det.py:71-90, :102-210
+ * for the segments it keeps (more than two points, :53-55), in its column order and with its data-set
+ * coupled definitions: ref_feat [B][max_seg][15] float64 =
+ *   0 n, 1 sigma, 2 ||segment - median||_F / n (:127-130), 3 jump to the previous kept segment,
+ *   4 jump to kept[min(q+1, 3)] (:133-138; NaN where the reference raises IndexError), 5 width,
+ *   6 line residual, 7 circle criterion, 8 radius, 9 boundary length, 10 boundary regularity,
+ *   11 summed curvature, 12 mean angular difference,
+ *   13 mean((next_ranges - ranges)[piece q of the unfiltered split] / (odom_dt + 1e-3)) (:196-203),
+ *   14 label (+1 when the segment centre lies within radius_wp of an annotation, else -1; :84-88).
+ * next_ranges [B][N] (NULL: column 13 = NaN), odom_dt [B] = next_odom - odom (NULL: 0),
+ * annotations as CSR wp_offsets [B+1] / wp_xy [W][2] (NULL: every label -1), num_kept [B] (may be NULL).
+ * feat (the 16-column table of pof_segment_features) and ref_feat may each be NULL, not both. */
+int pof_segment_features_ex(const float *ranges, const float *next_ranges, const double *tab, int B, int N,
+                            double jump_dist, const double *odom_dt, const int32_t *wp_offsets,
+                            const double *wp_xy, double radius_wp, int max_seg, int32_t *seg_id,
+                            int32_t *num_seg, int32_t *num_kept, double *feat, double *ref_feat,
+                            pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A16 rotate_iou_gpu_eval                     src/utils/rotate_iou.py:297-404
  * boxes [N][5|7], query [K][5|7] float32 (already permuted to the kernel's

@@ -501,6 +501,66 @@ def segment_features(scan, phi, jump_dist=0.5):
     return cuts, out
 
 
+def segment_labels(scan, phi, wps, radius_wp=0.5, jump_dist=0.5):
+    """scan_to_segments (:71-90) -> (segments [list of (n,2)], labels [S], cut_ids)."""
+    xy = np.array(polar_to_xy(scan, phi)).T
+    cuts = segment_cuts(scan, jump_dist)
+    segs = np.split(xy, cuts, axis=0)
+    labels = -1.0 * np.ones(len(segs))
+    for i, seg in enumerate(segs):
+        c = np.mean(seg, axis=0)
+        if any(np.linalg.norm(c - np.asarray(wp)) <= radius_wp for wp in wps):
+            labels[i] = 1.0
+    return segs, labels, cuts
+
+
+def compute_feature_reference(scan, phi, wps, next_scan, odom, next_odom, radius_wp=0.5, jump_dist=0.5):
+    """Dataset.compute_feature (:102-210) for one scan, as the reference executes it -- all 14 columns plus
+    the label, *including* the three that are coupled to the data set's bookkeeping:
+
+      2  "median deviation"  = ||segment - median||_F / n          (:127-130: norm without an axis)
+      3  preceding jump      = to the last point of the previous KEPT segment (segments of <= 2 points
+                               were dropped before, :53-55)
+      4  succeeding jump     = to the first point of kept[min(idx + 1, len(data) - 1)] with data the
+                               4-element record [segments, cut_ids, scan, odom]  (:135: always min(idx + 1, 3);
+                               fewer than four kept segments raise IndexError there, NaN here)
+      13 mean speed          = mean((next_scan - scan)[piece idx of the UNFILTERED split] / (next_odom - odom
+                               + 1e-3)), idx counting kept segments (:196-203)
+
+    -> (K, 15) float64, K = number of segments with more than two points."""
+    segs, labels, cuts = segment_labels(scan, phi, wps, radius_wp, jump_dist)
+    kept = [(s, l) for s, l in zip(segs, labels) if len(s) > 2]
+    cur_pieces = np.split(np.asarray(scan, dtype=np.float64), cuts)
+    next_pieces = np.split(np.asarray(next_scan, dtype=np.float64), cuts)
+    rows = []
+    for q, (seg, label) in enumerate(kept):
+        n = len(seg)
+        mean = np.mean(seg, axis=0)
+        d = np.linalg.norm(seg - mean, axis=-1)
+        sigma = np.sqrt(np.sum(np.square(d))) / (n - 1)
+        med = np.median(seg, axis=0)
+        med_dev = np.linalg.norm(seg - med) / n
+        prev = kept[max(0, q - 1)][0]
+        jump_prev = np.linalg.norm(prev[-1] - seg[0])
+        nq = min(q + 1, 3)
+        jump_next = np.linalg.norm(seg[-1] - kept[nq][0][0]) if nq < len(kept) else np.nan
+        width = np.linalg.norm(seg[-1] - seg[0])
+        _, _, res = fit_line(seg)
+        _, _, rc, sc = fit_circle(seg)
+        e = np.linalg.norm(seg[1:] - seg[:-1], axis=-1)
+        a, b_, c = seg[:-2], seg[1:-1], seg[2:]
+        da, db, dc = (np.linalg.norm(b_ - a, axis=-1), np.linalg.norm(c - b_, axis=-1),
+                      np.linalg.norm(a - c, axis=-1))
+        area = np.abs(0.5 * (a[:, 0] * (b_[:, 1] - c[:, 1]) + b_[:, 0] * (c[:, 1] - a[:, 1])
+                             + c[:, 0] * (a[:, 1] - b_[:, 1])))
+        ba, bc = a - b_, c - b_
+        cosv = np.einsum("ij,ij->i", ba, bc) / (np.linalg.norm(ba, axis=-1) * np.linalg.norm(bc, axis=-1))
+        speed = np.mean((next_pieces[q] - cur_pieces[q]) / (next_odom - odom + 1e-3))
+        rows.append([n, sigma, med_dev, jump_prev, jump_next, width, res, sc, rc, e.sum(), e.std(),
+                     np.sum(4 * area / (da * db * dc)), np.mean(np.arccos(cosv)), speed, label])
+    return np.array(rows, dtype=np.float64).reshape(-1, 15)
+
+
 # --------------------------------------------------------------------------
 # N4 boosted decision stumps     src/depracted/model/adaboost_person_det.py:11-37, 212-378
 # --------------------------------------------------------------------------

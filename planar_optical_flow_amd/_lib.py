@@ -49,6 +49,7 @@ SIGNATURES = {
     "pof_spatial_attention_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
     "pof_spatial_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "pof_segment_features": (_i, [_p, _p, _i, _i, _d, _i, _p, _p, _p, _p]),
+    "pof_segment_features_ex": (_i, [_p, _p, _p, _i, _i, _d, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _p]),
     "pof_gather_windows": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p]),
     "pof_associate_odometry": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),

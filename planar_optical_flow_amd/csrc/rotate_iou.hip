@@ -20,7 +20,10 @@ struct Pt {
 __device__ __forceinline__ void box_corners(const float *b, float *c)
 {
     const float ang = b[4];
-    const float ac = cosf(ang), as = sinf(ang);
+    // correctly rounded float32 cos / sin (float64 evaluation rounded once): what the reference's device
+    // functions give when they run as plain Python (tools/gen_golden.py), and what the oracle computes.
+    // Degenerate pairs (identical rotated boxes) flip between 0 and 1 on the last bit of these two values.
+    const float ac = (float)cos((double)ang), as = (float)sin((double)ang);
     const float hx = b[2] / 2.0f, hy = b[3] / 2.0f;
     const float xs[4] = {-hx, -hx, hx, hx};
     const float ys[4] = {-hy, hy, hy, -hy};

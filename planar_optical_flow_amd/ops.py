@@ -576,6 +576,41 @@ def segment_features(ranges, tab, jump_dist=0.5, max_seg=None):
     return seg_id, num, feat
 
 
+def segment_features_reference(ranges, tab, next_ranges=None, odom_dt=None, wp_offsets=None, wp_xy=None,
+                               radius_wp=0.5, jump_dist=0.5, max_seg=None, want_plain=False):
+    """A13 in the reference's own form (compute_feature, adaboost_person_det.py:102-210): ranges [B,N] float32
+    -> (seg_id [B,N], num_seg [B], num_kept [B], ref_feat [B,max_seg,15] float64[, feat [B,max_seg,16]]).
+    next_ranges [B,N] float32 and odom_dt [B] float64 feed the mean-speed column, the annotation CSR
+    (wp_offsets [B+1] int32, wp_xy [W,2] float64) the labels."""
+    ranges = _dev(ranges, torch.float32, "ranges")
+    B, N = ranges.shape
+    if next_ranges is not None:
+        next_ranges = _dev(next_ranges, torch.float32, "next_ranges")
+        if next_ranges.shape != ranges.shape:
+            raise ValueError("next_ranges must have the shape of ranges")
+    if odom_dt is not None:
+        odom_dt = _dev(odom_dt, torch.float64, "odom_dt")
+        if odom_dt.numel() != B:
+            raise ValueError("odom_dt must be [B]")
+    if wp_offsets is not None:
+        wp_offsets = _dev(wp_offsets, torch.int32, "wp_offsets")
+        wp_xy = _dev(wp_xy, torch.float64, "wp_xy")
+        if wp_offsets.numel() != B + 1 or wp_xy.dim() != 2 or wp_xy.shape[1] != 2:
+            raise ValueError("annotations must be CSR: wp_offsets [B+1], wp_xy [W,2]")
+    max_seg = N if max_seg is None else int(max_seg)
+    dev = ranges.device
+    seg_id = torch.empty((B, N), dtype=torch.int32, device=dev)
+    num = torch.empty(B, dtype=torch.int32, device=dev)
+    kept = torch.empty(B, dtype=torch.int32, device=dev)
+    ref = torch.full((B, max_seg, 15), float("nan"), dtype=torch.float64, device=dev)
+    feat = torch.full((B, max_seg, 16), float("nan"), dtype=torch.float64, device=dev) if want_plain else None
+    with torch.cuda.device(dev):
+        _lib.call("pof_segment_features_ex", _ptr(ranges), _ptr(next_ranges), _ptr(tab), B, N, float(jump_dist),
+                  _ptr(odom_dt), _ptr(wp_offsets), _ptr(wp_xy), float(radius_wp), max_seg, _ptr(seg_id), _ptr(num),
+                  _ptr(kept), _ptr(feat), _ptr(ref), _stream())
+    return (seg_id, num, kept, ref, feat) if want_plain else (seg_id, num, kept, ref)
+
+
 _PERM_3D = [0, 1, 3, 4, 6, 2, 5]
 
 

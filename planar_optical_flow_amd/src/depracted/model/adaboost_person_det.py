@@ -154,41 +154,48 @@ def nms_predicted_center(data, preds, scores, min_dist=1.0):
     return segments, preds, scores
 
 
-# feature columns of pof_segment_features used for boosting (n, sigma, jumps, width, line residual, circle
-# criterion, radius, boundary length / regularity, curvature, mean angular difference)
-FEATURE_COLUMNS = tuple(range(12))
-
-
 class SegmentDataset:
     """Segments of many scans with their boosting features and labels (reference ``Dataset``, :39-210).
 
-    scans [S, N] ranges; dets: per scan a list / array of annotated xy positions.  A segment is positive when
-    its centre lies within ``radius_wp`` of an annotation (:84-88); segments of fewer than three points are
-    dropped (:53-55).  Features come from one ``pof_segment_features`` launch; of the reference's list the
-    median deviation (a Frobenius norm there), the succeeding jump distance (indexed with the wrong length)
-    and the mean speed (needs the next scan's odometry) are not reproduced -- see oracle/ref_numpy.py A13."""
+    scans [S, N] ranges; dets: per scan a list / array of annotated xy positions; odom_t [S]: the per-scan
+    odometry value the reference keeps as ``data[-1]`` (default zeros).  A segment is positive when its centre lies
+    within ``radius_wp`` of an annotation (:84-88); segments of fewer than three points are dropped (:53-55).
+    ``input`` is the reference's table: its 14 columns in its order, *with* its data-set coupled definitions
+    (Frobenius "median deviation", succeeding jump to kept[min(idx + 1, 3)], mean speed over the idx-th piece of
+    the unfiltered split against the next scan of the set, next = min(idx + 1, S - 1)); like the reference it raises
+    IndexError for a scan with fewer than four kept segments.  All of it comes from one ``pof_segment_features_ex``
+    launch (one wave per segment)."""
 
-    def __init__(self, scans, dets, angle_inc=np.radians(0.5), radius_wp=0.5, jump_dist=0.5, device="cuda"):
+    def __init__(self, scans, dets, odom_t=None, angle_inc=np.radians(0.5), radius_wp=0.5, jump_dist=0.5,
+                 device="cuda"):
         scans = torch.as_tensor(np.asarray(scans, dtype=np.float32)).to(device)
         S, N = scans.shape
-        tab = ops.phi_table(angle_inc, N, device=scans.device)
-        seg_id, num, feat = ops.segment_features(scans, tab, jump_dist=jump_dist)
+        dev = scans.device
+        tab = ops.phi_table(angle_inc, N, device=dev)
+        nxt = scans[torch.clamp(torch.arange(S, device=dev) + 1, max=max(S - 1, 0))].contiguous()
+        ot = np.zeros(S) if odom_t is None else np.asarray(odom_t, dtype=np.float64).reshape(S)
+        dt = torch.from_numpy(ot[np.minimum(np.arange(S) + 1, max(S - 1, 0))] - ot).to(dev)
+        wps = [np.asarray(d, dtype=np.float64).reshape(-1, 2) for d in dets]
+        offs = np.zeros(S + 1, dtype=np.int32)
+        offs[1:] = np.cumsum([len(w) for w in wps])
+        wxy = np.concatenate(wps + [np.zeros((1, 2))])              # one spare row keeps the pointer valid
+        seg_id, num, kept, ref = ops.segment_features_reference(
+            scans, tab, nxt, dt, torch.from_numpy(offs).to(dev), torch.from_numpy(wxy).to(dev),
+            radius_wp=radius_wp, jump_dist=jump_dist)
         xy = ops.scan_preprocess(scans, tab, want=("xy",), out_dtype=torch.float64)["xy"]
-        seg_id_h, num_h, feat_h, xy_h = seg_id.cpu().numpy(), num.cpu().numpy(), feat.cpu().numpy(), xy.cpu().numpy()
+        seg_id_h, kept_h, ref_h, xy_h = seg_id.cpu().numpy(), kept.cpu().numpy(), ref.cpu().numpy(), xy.cpu().numpy()
         self.scans_feature, self.labels, self.segments = [], [], []
         for s in range(S):
-            f = feat_h[s, :num_h[s]]
-            keep = f[:, 0] > 2
-            segs = [xy_h[s][seg_id_h[s] == q] for q in np.nonzero(keep)[0]]
-            wps = np.asarray(dets[s], dtype=np.float64).reshape(-1, 2)
-            lab = -np.ones(len(segs))
-            for q, seg in enumerate(segs):
-                if len(wps) and np.any(np.linalg.norm(seg.mean(axis=0) - wps, axis=1) <= radius_wp):
-                    lab[q] = 1.0
-            self.scans_feature.append(f[keep][:, FEATURE_COLUMNS])
-            self.labels.append(lab)
-            self.segments.append([[seg, l] for seg, l in zip(segs, lab)])
-        self.input = np.vstack(self.scans_feature) if S else np.zeros((0, len(FEATURE_COLUMNS)))
+            K = int(kept_h[s])
+            if K < 4:
+                raise IndexError("list index out of range")     # the reference's segments[min(idx + 1, 3)] (:135)
+            f = ref_h[s, :K]
+            ids, counts = np.unique(seg_id_h[s], return_counts=True)
+            segs = [xy_h[s][seg_id_h[s] == q] for q in ids[counts > 2]]
+            self.scans_feature.append(f[:, :14])
+            self.labels.append(f[:, 14].copy())
+            self.segments.append([[seg, l] for seg, l in zip(segs, f[:, 14])])
+        self.input = np.vstack(self.scans_feature) if S else np.zeros((0, 14))
         self.target = np.hstack(self.labels) if S else np.zeros(0)
 
     def __len__(self):

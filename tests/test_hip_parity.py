@@ -238,17 +238,20 @@ def test_cutout_bit_exact_vs_oracle(ops, golden, name):
 
 @pytest.mark.parametrize("name", list(CUTOUT_CASES))
 def test_cutout_vs_reference_golden(ops, golden, name):
-    """Against the reference's own output (np.arctan on float32, last bit CPU
-    dependent): identical except where that last bit moves an index across an
-    integer; stated tolerance: <= 0.2 % of elements differ by more than 1e-4."""
-    g = golden("cutout")
+    """Against the reference's own output and its own internal inds_ct_low (tests/golden/cutout_indices.npz).
+    The reference evaluates np.arctan on float32 (last bit CPU dependent), the kernel the correctly rounded
+    value: on these fixtures no index moves, and at most 1.4e-5 of the values (area-mode samples whose rint
+    flips) differ by more than 1e-4 -- stated bound 5e-5."""
+    g, gi = golden("cutout"), golden("cutout_indices")
     inc, n, kw = CUTOUT_CASES[name]
     tab = ops.phi_table(np.radians(inc), n)
-    got = ops.cutout(T(g[name + "_scans"]), tab, **kw).cpu().numpy()
+    got, dbg = ops.cutout(T(g[name + "_scans"]), tab, return_debug=True, **kw)
+    got = got.cpu().numpy()
     want = g[name + "_out"]
     assert got.shape == want.shape
+    assert np.array_equal(dbg["lo"].cpu().numpy(), gi[name + "_lo"]), "inds_ct_low must equal the reference's"
     frac = np.mean(np.abs(got - want) > 1e-4)
-    assert frac < 2e-3, frac
+    assert frac <= 5e-5, frac
 
 
 def test_cutout_batch_properties(ops):
@@ -439,6 +442,20 @@ def test_rotate_iou_known_answers(ops):
     np.testing.assert_allclose(got, [1.0, 0.0, 1 / 3, oct_ / (2 - oct_)], rtol=1e-5, atol=1e-7)
 
 
+@pytest.mark.parametrize("tag,is_3d", [("2d", False), ("3d", True)])
+def test_rotate_iou_reference_vectors(ops, golden, tag, is_3d):
+    """The reference's own device functions on random rotated boxes (tests/golden/rotate_iou.npz), every
+    criterion: the reference's float32 tolerance 1e-5, and -- same operation order, correctly rounded
+    cos / sin / sqrt / divide -- in fact identical, incl. the box-against-itself pair (0, 0) that the
+    reference decides on the last bit."""
+    g = golden("rotate_iou")
+    for crit in (-1, 0, 1, 2):
+        key = "%s_c%d" % (tag, crit)
+        got = ops.rotate_iou(T(g[key + "_boxes"]), T(g[key + "_query"]), criterion=crit, is_3d=is_3d).cpu().numpy()
+        np.testing.assert_allclose(got, g[key + "_iou"], rtol=0, atol=1e-5)
+        assert np.array_equal(got, g[key + "_iou"]), (key, np.abs(got - g[key + "_iou"]).max())
+
+
 def test_rotate_iou_vs_oracle(ops):
     rng = np.random.default_rng(16)
 
@@ -601,6 +618,47 @@ def test_chained_preprocess_equals_two_launch_form(ops):
             assert torch.equal(got[k], ref[i][k]), (i, k)
 
 
+def test_chained_f32_preprocess_b4096_vs_oracle(ops):
+    """The instantiation bench.py times -- pof_scan_preprocess_chained, float32 outputs, B = 4096, 450 points
+    (BASELINE config 2) -- against the oracle on every 29th sample: association bit-exact, masks bit-exact,
+    target_reg <= 1e-6, flow EPE <= 1e-5 m (north_star bar 1e-4 m)."""
+    B = 4096
+    tab = ops.phi_table()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+    sbs = [synth.make_batch(seed=s, B=B, T=2) for s in (2, 1002)]
+    dev = []
+    for sb in sbs:
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        dev.append((T(sb.scans), T(sb.odom0), T(sb.odom1), det, ws))
+    s, o0, o1, d, ws = dev[0]
+    ops.scan_preprocess(s, tab, o0, o1, d, want=want, workspace=ws, phases=1)          # prime batch 0
+    phi = R.laser_phi()
+    for i in (0, 1):
+        s, o0, o1, d, ws = dev[i]
+        ns, n0, n1, nd, nws = dev[1 - i]
+        out = ops.scan_preprocess(s, tab, o0, o1, d, want=want, workspace=ws,
+                                  next_batch={"odom0": n0, "odom1": n1, "dets": nd, "workspace": nws})
+        assert out["flow"].dtype == torch.float32
+        flow, cls = out["flow"].cpu().numpy(), out["target_cls"].cpu().numpy()
+        reg, exc = out["target_reg"].cpu().numpy(), out["exclude_mask"].cpu().numpy()
+        sb = sbs[i]
+        epe, hits = [], 0
+        for b in range(0, B, 29):
+            cur = sb.scans[b, -1]
+            xy = np.array(R.polar_to_xy(cur, phi)).T
+            wf = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
+            epe.append(np.linalg.norm(flow[b].astype(np.float64) - wf, axis=-1).mean())
+            dd = sb.dets[b]
+            c, r = R.regression_target(cur, phi, dd["wc"], dd["wa"], dd["wp"])
+            assert np.array_equal(cls[b], c), (i, b)
+            np.testing.assert_allclose(reg[b], r, rtol=0, atol=1e-6)
+            m = R.dynamic_mask(xy, dd["wc"], dd["wa"], dd["wp"]) * R.valid_point_mask(cur)
+            assert np.array_equal(exc[b].astype(np.float64), m), (i, b)
+            hits += int((c > 0).sum())
+        assert max(epe) < 1e-5 and hits > 0, (max(epe), hits)
+
+
 @pytest.mark.parametrize("name", sorted(CUTOUT_CASES))
 def test_cutout_float32_value_path(ops, golden, name):
     """value_mode 1 (approximate-then-verify index, float32 lerp): inds_ct_low identical to the
@@ -737,3 +795,72 @@ def test_spatial_attention_float16_storage(ops):
     wo, _ = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
                                 t.astype(np.float64), 0.5, 11)
     np.testing.assert_allclose(oh.float().cpu().numpy(), wo, rtol=2e-3, atol=2e-3)
+
+
+# ---------------------------------------------------------------- BASELINE config 5 at its stated size
+_DENSE_KW = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+                 padding_val=29.99, area_mode=True)
+
+
+def test_config5_cutout_3600x11_f16(ops, golden):
+    """N = 3600, T = 11, float16 output (configs[4]): (i) against the oracle with the kernel's half-angle
+    definition on a batch of 3 windows -- float32 result bit-exact, float16 result = that rounded once, indices
+    and s_area bit-exact; (ii) against the reference's own output and indices for the window of
+    tests/golden/cutout_dense.npz (every 4th point stored)."""
+    g, gi = golden("cutout_dense"), golden("cutout_indices")
+    tab = ops.phi_table(np.radians(0.1), 3600)
+    phi = R.laser_phi(np.radians(0.1), 3600)
+    sb = synth.make_batch(seed=55, B=2, T=11, N=3600, angle_inc=np.radians(0.1))
+    scans = np.concatenate([g["scans"], sb.scans])
+    scans[2, :, 100:160] = 0.4                                   # a near-field object: wide area-sampled windows
+    full, dbg = ops.cutout(T(scans), tab, return_debug=True, **_DENSE_KW)
+    half = ops.cutout(T(scans), tab, out_dtype=torch.float16, **_DENSE_KW)
+    assert half.dtype == torch.float16 and tuple(half.shape) == (3, 3600, 11, 56)
+    assert torch.equal(half, full.to(torch.float16))
+    full, half, lo = full.cpu().numpy(), half.cpu().numpy(), dbg["lo"].cpu().numpy()
+    s_areas = set()
+    for b in range(3):
+        want, wd = R.cutout(scans[b], phi, atan_mode="cr", return_debug=True, **_DENSE_KW)
+        assert np.array_equal(lo[b], wd["lo"])
+        assert int(dbg["s_area"][b].item()) == wd["s_area"]
+        assert np.array_equal(full[b], want)
+        assert np.array_equal(half[b], want.astype(np.float16))
+        s_areas.add(wd["s_area"])
+    assert len(s_areas) > 1                                      # per-sample area factors really differ
+    st = int(g["point_stride"])
+    assert np.array_equal(lo[0][:, :, ::st], gi["dense_t11_lo"][0])
+    assert np.mean(np.abs(full[0][::st] - g["out"][0]) > 1e-4) <= 5e-5
+    assert np.mean(np.abs(half[0][::st].astype(np.float32) - g["out"][0]) > 1e-3) <= 5e-5
+
+
+def test_config5_spatial_attention_n3600(ops):
+    """The gate at N = 3600 points, E = 128, w = 11, F = 256 x 14 (configs[4]; the reference forms the dense
+    3600 x 3600 similarity, dr_spaam.py:184-187): float32 and float16-storage kernels against the oracle."""
+    rng = np.random.default_rng(505)
+    B, N, E, F = 1, 3600, 128, 3584
+    ex = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    et = rng.normal(0, 0.3, (B, N, E)).astype(np.float32)
+    x = rng.normal(0, 1, (B, N, F)).astype(np.float16)
+    t = rng.normal(0, 1, (B, N, F)).astype(np.float16)
+    wo, wb = R.spatial_attention(ex.astype(np.float64), et.astype(np.float64), x.astype(np.float64),
+                                 t.astype(np.float64), 0.5, 11)
+    of, bf, pf = ops.spatial_attention(T(ex), T(et), T(x.astype(np.float32)), T(t.astype(np.float32)), 0.5, 11)
+    np.testing.assert_allclose(bf.cpu().numpy(), wb, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(of.cpu().numpy(), wo, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(pf.sum(-1).cpu().numpy(), 1.0, rtol=1e-5)
+    oh, bh, ph = ops.spatial_attention(T(ex), T(et), T(x), T(t), 0.5, 11)
+    assert oh.dtype == torch.float16
+    assert torch.equal(bh, bf) and torch.equal(ph, pf)
+    assert torch.equal(oh, of.to(torch.float16))
+    np.testing.assert_allclose(oh.float().cpu().numpy(), wo, rtol=2e-3, atol=2e-3)
+
+
+def test_config5_band_correlation_n450_f16(ops):
+    """configs[4] 'fp16 correlation': the Prototype's cost volume on float16 features of a 3600-point scan after
+    the three stride-2 encoder stages (n = 450), C = 256, against the oracle."""
+    rng = np.random.default_rng(506)
+    f1 = rng.normal(0, 1, (2, 256, 450)).astype(np.float16)
+    f2 = rng.normal(0, 1, (2, 256, 450)).astype(np.float16)
+    got = ops.band_correlation(T(f1), T(f2), 3, 5).cpu().numpy()
+    want = R.band_correlation(f1.astype(np.float64), f2.astype(np.float64), 3, 5)
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)

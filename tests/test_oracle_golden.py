@@ -114,6 +114,36 @@ def test_a8_atan_modes_are_close(golden):
     assert frac < 2e-3
 
 
+def test_a8_indices_equal_the_references_own(golden):
+    """inds_ct_low as the reference computed it internally (captured by tools/gen_golden.py around its np.floor):
+    the oracle reproduces it in both arctangent modes on every fixture -- the correctly rounded half-angle moves
+    no index on these scans, only a few area-mode samples (next test)."""
+    g, gi = golden("cutout"), golden("cutout_indices")
+    for name, (inc, n, kw) in CUTOUT_CASES.items():
+        phi = R.laser_phi(np.radians(inc), n)
+        for b in range(len(g[name + "_scans"])):
+            for mode in ("numpy", "cr"):
+                out, dbg = R.cutout(g[name + "_scans"][b], phi, atan_mode=mode, return_debug=True, **kw)
+                assert np.array_equal(dbg["lo"], gi[name + "_lo"][b]), (name, b, mode)
+                # measured: at most 1.4e-5 of the values differ by more than 1e-4 from the reference's output
+                assert np.mean(np.abs(out - g[name + "_out"][b]) > 1e-4) <= 5e-5, (name, b, mode)
+
+
+def test_a8_cutout_config5_at_size(golden):
+    """BASELINE config 5: 3600 points x 11 scans through the reference (every 4th point stored)."""
+    g, gi = golden("cutout_dense"), golden("cutout_indices")
+    inc, n, kw = CUTOUT_CASES["dense3600"]
+    phi = R.laser_phi(np.radians(inc), n)
+    st = int(g["point_stride"])
+    out, dbg = R.cutout(g["scans"][0], phi, return_debug=True, **kw)
+    assert out.shape == (3600, 11, 56)
+    assert np.array_equal(out[::st], g["out"][0])
+    assert np.array_equal(dbg["lo"][:, :, ::st], gi["dense_t11_lo"][0])
+    out_cr, dbg_cr = R.cutout(g["scans"][0], phi, atan_mode="cr", return_debug=True, **kw)
+    assert np.array_equal(dbg_cr["lo"], dbg["lo"])
+    assert np.mean(np.abs(out_cr - out) > 1e-4) <= 5e-5
+
+
 def test_a11_nms(golden):
     g = golden("nms")
     for k in range(3):
@@ -165,6 +195,24 @@ def test_a16_rotate_iou_known_answers():
     oct_ = 2 * (np.sqrt(2) - 1)
     np.testing.assert_allclose(R.rotate_iou(sq, np.array([[0, 0, 1, 1, np.pi / 4]]))[0, 0],
                                oct_ / (2 - oct_), rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag,is_3d", [("2d", False), ("3d", True)])
+def test_a16_rotate_iou_reference_vectors(golden, tag, is_3d):
+    """tests/golden/rotate_iou.npz: the reference's own devRotateIoU2dEval / devRotateIoU3dEval
+    (src/utils/rotate_iou.py:248-293 and everything they call, run as plain Python by tools/gen_golden.py) on
+    random rotated boxes, every criterion.  Same float32 operation order -> identical."""
+    g = golden("rotate_iou")
+    for crit in (-1, 0, 1, 2):
+        key = "%s_c%d" % (tag, crit)
+        got = R.rotate_iou(g[key + "_boxes"], g[key + "_query"], criterion=crit, is_3d=is_3d)
+        want = g[key + "_iou"]
+        assert got.shape == want.shape == (12, 10)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-7)
+        assert (want > 0.01).sum() >= 40 and want[2, 2] == 0.0
+    # pair (0, 0) is a box against itself: the reference's containment / crossing tests decide it on the last
+    # bit (0, 0.5 and 1 all occur in the fixture) -- the restatement follows it through those as well
+    assert g["2d_c-1_iou"][0, 0] == 0.0 and abs(g["2d_c0_iou"][0, 0] - 0.5) < 1e-6 and g["3d_c-1_iou"][0, 0] > 0.999
 
 
 def test_a13_fits_against_lapack():

@@ -49,14 +49,137 @@ def _install_stubs():
 
     nb.jit = cu.jit = jit
     nb.cuda = cu
+    # the device functions of src/utils/rotate_iou.py are plain Python once these exist
+    nb.float32 = np.float32
+    cu.local = types.SimpleNamespace(array=lambda shape, dtype: np.zeros(shape, dtype=dtype))
     np.int = int
     np.float = float
     torch.Tensor.cuda = lambda s, *a, **k: s
     sys.path.insert(0, REF)
 
 
+def gen_rotate_iou():
+    """A16: the reference's own device functions (src/utils/rotate_iou.py:20-294) run as plain
+    Python (numba.cuda.jit is a pass-through, cuda.local.array -> np.zeros) on random rotated boxes,
+    with the host wrapper's float32 cast and 3-D column permutation (:378-384) and the kernel's
+    argument order (query box first, :346-357)."""
+    import src.utils.rotate_iou as rot
+    rng = np.random.default_rng(1601)
+    g = {}
+    perm = [0, 1, 3, 4, 6, 2, 5]
+
+    def boxes2d(n, spread):
+        return np.stack([rng.uniform(-spread, spread, n), rng.uniform(-spread, spread, n),
+                         rng.uniform(0.2, 2.0, n), rng.uniform(0.2, 2.0, n),
+                         rng.uniform(-np.pi, np.pi, n)], axis=1)
+
+    def boxes3d(n, spread):
+        b = boxes2d(n, spread)                       # x y l w rot -> x y z l w h rot
+        return np.stack([b[:, 0], b[:, 1], rng.uniform(-0.5, 0.5, n), b[:, 2], b[:, 3],
+                         rng.uniform(0.5, 2.0, n), b[:, 4]], axis=1)
+
+    with np.errstate(all="ignore"):
+        for tag, is_3d, mk in (("2d", False, boxes2d), ("3d", True, boxes3d)):
+            for crit in (-1, 0, 1, 2):
+                N, K = 12, 10
+                bx, qx = mk(N, 1.0), mk(K, 1.0)
+                # special pairs: identical, concentric with another angle, far apart, touching edge
+                qx[0] = bx[0]
+                qx[1] = bx[1]; qx[1][-1] += 0.7
+                qx[2][:2] = bx[2][:2] + 50.0
+                b32, q32 = bx.astype(np.float32), qx.astype(np.float32)
+                if is_3d:
+                    b32, q32 = b32[:, perm], q32[:, perm]
+                fn = rot.devRotateIoU3dEval if is_3d else rot.devRotateIoU2dEval
+                out = np.zeros((N, K), dtype=np.float32)
+                for i in range(N):
+                    for k in range(K):
+                        out[i, k] = fn(q32[k].copy(), b32[i].copy(), crit)
+                key = "%s_c%d" % (tag, crit)
+                g[key + "_boxes"], g[key + "_query"], g[key + "_iou"] = bx, qx, out
+    np.savez_compressed(os.path.join(OUT, "rotate_iou.npz"), **g)
+    print("rotate_iou.npz:", {k: v.shape for k, v in g.items() if k.endswith("_iou")})
+
+
+class _FloorRecorder:
+    """Stands in for the `np` name inside src.utils.utils while scans_to_cutout runs: every attribute
+    is numpy's, `floor` additionally keeps its result, so that the reference's *internal* inds_ct_low
+    (utils.py:292: clip(floor(inds_ct), 0, N-1)) can be stored next to its output."""
+
+    def __init__(self):
+        self.floors = []
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    def floor(self, x):
+        r = np.floor(x)
+        self.floors.append(r)
+        return r
+
+
+def _reference_cutout_with_indices(u, scans, phi, **kw):
+    rec = _FloorRecorder()
+    u.np = rec
+    try:
+        out = u.scans_to_cutout(scans, phi, **kw)
+    finally:
+        u.np = np
+    assert len(rec.floors) == 1
+    lo = np.clip(rec.floors[0], 0, scans.shape[1] - 1).astype(np.int16)      # (P, T, N/stride)
+    return out, lo
+
+
+def gen_cutout_indices():
+    """The reference's own inds_ct_low for every fixture of cutout.npz (same seeds) and for the dense
+    config-5 window of cutout_dense.npz (every 4th point)."""
+    import src.utils.utils as u
+    from planar_optical_flow_amd import synth
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    from cases import CUTOUT_CASES
+    gold = np.load(os.path.join(OUT, "cutout.npz"))
+    g = {}
+    for name, (inc, n, kw) in CUTOUT_CASES.items():
+        scans = gold[name + "_scans"]
+        ph = u.get_laser_phi(np.radians(inc), n)
+        los = []
+        for b in range(len(scans)):
+            out, lo = _reference_cutout_with_indices(u, scans[b], ph, **kw)
+            assert np.array_equal(out, gold[name + "_out"][b]), name
+            los.append(lo)
+        g[name + "_lo"] = np.array(los)
+    dense = np.load(os.path.join(OUT, "cutout_dense.npz"))
+    ph = u.get_laser_phi(np.radians(0.1), 3600)
+    out, lo = _reference_cutout_with_indices(u, dense["scans"][0], ph, **CUTOUT_CASES["dense3600"][2])
+    assert np.array_equal(out[::4], dense["out"][0])
+    g["dense_t11_lo"] = lo[None, :, :, ::4]
+    np.savez_compressed(os.path.join(OUT, "cutout_indices.npz"), **g)
+    print("cutout_indices.npz:", {k: v.shape for k, v in g.items()})
+
+
+def gen_cutout_dense():
+    """BASELINE config 5 at size: one 3600-point, 11-scan window through the reference's cutout."""
+    import src.utils.utils as u
+    from planar_optical_flow_amd import synth
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=56,
+              padding_val=29.99, area_mode=True)
+    sb = synth.make_batch(seed=105, B=1, T=11, N=3600, angle_inc=np.radians(0.1))
+    ph = u.get_laser_phi(np.radians(0.1), 3600)
+    out = u.scans_to_cutout(sb.scans[0], ph, **kw)
+    # (3600, 11, 56) float32 = 8.9 MB raw: every 4th point is stored (points are independent given
+    # the call-wide s_area, which the full call above fixed)
+    np.savez_compressed(os.path.join(OUT, "cutout_dense.npz"), scans=sb.scans, point_stride=np.array(4),
+                        out=out[None, ::4])
+    print("cutout_dense.npz:", out.shape, out.dtype)
+
+
 def main():
     _install_stubs()
+    if "--only" in sys.argv:
+        os.makedirs(OUT, exist_ok=True)
+        for name in sys.argv[sys.argv.index("--only") + 1:]:
+            globals()["gen_" + name]()
+        return
     import src.utils.utils as u
     from src.utils.dataset_dr_spaam import DROWDataset2
     from src.depracted.model import prototype as proto
@@ -563,6 +686,10 @@ def main():
     gq["train_out"] = pref(s1, s2).detach().numpy()
     gq["s1"], gq["s2"] = s1.numpy(), s2.numpy()
     np.savez_compressed(os.path.join(OUT, "prototype_model.npz"), **gq)
+
+    gen_rotate_iou()
+    gen_cutout_dense()
+    gen_cutout_indices()
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)
