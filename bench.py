@@ -9,8 +9,17 @@ pof_scan_preprocess over one batch per rank (scan -> xy -> rigid-motion flow ->
 canonical frame, detection association, regression target, exclude mask).
 Inputs are resident in HBM before the timed region; a ring of distinct batches
 larger than the 256 MiB Infinity Cache is cycled so the stream really comes from
-HBM.  Batches shard over ranks with no data-path collective (weak scaling: every
-rank processes its own 4096 scans per step).
+HBM.  Batches shard over ranks with no data-path collective.  `value` is the weak
+form (every rank processes its own 4096 scans per step); for N > 1 the line also
+carries SURVEY 8(e)'s strong split (the 4096-scan batch cut into 4096 / N per rank)
+as `strong_scaling`.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks
+itself (one fresh child process per GPU, before anything here touches HIP) and
+relays rank 0's JSON line; under torch.distributed.run the ranks are taken from
+the environment as usual.  The K-step region is timed `--repeats` times (default 5),
+each bracketed by barrier + synchronize and maximised over ranks; the line reports
+the median (and min / max).
 
 One JSON line on stdout (rank 0).  Extra objects:
   roofline      dominant kernel of the headline step (scan_preprocess_kernel)
@@ -71,6 +80,8 @@ def parse():
     ap.add_argument("--no-model", action="store_true",
                     help="skip the DR-SPAAM forward extra (PMC passes: keeps the per-kernel averages per shape)")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
+    ap.add_argument("--spawn", action="store_true", help="start the rank processes from this one even for --gpus 1")
     return ap.parse_args()
 
 
@@ -94,36 +105,101 @@ def cpu_sample_worker(args):
     return [np.array([o[k] for o in out]) for k in range(4)]
 
 
-def cpu_baseline(sb, budget_s=12.0):
+def host_cores():
+    """(physical cores per lscpu, CPUs this process may use: affinity mask capped by the cgroup CPU quota)."""
+    import subprocess
+    phys = None
+    try:
+        txt = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        kv = dict((l.split(":", 1)[0].strip(), l.split(":", 1)[1].strip()) for l in txt.splitlines() if ":" in l)
+        phys = int(kv["Core(s) per socket"]) * int(kv["Socket(s)"])
+        model = kv.get("Model name", "?")
+    except Exception:  # noqa: BLE001
+        model = "?"
+    usable = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            usable = min(usable, max(1, int(quota) // int(period)))
+    except Exception:  # noqa: BLE001
+        pass
+    return phys or usable, usable, model
+
+
+def cpu_baseline(sb, budget_s=20.0):
+    """the NumPy oracle in the reference's execution shape (one __getitem__-style call per sample +
+    collate), (i) one process, (ii) a pool of n processes, OMP_NUM_THREADS = 1 per worker, warm-up one batch,
+    >= 3 repeats, median.  n = the physical cores of the host, capped by what this box lets the process use (the
+    1-GPU boxes of this pool run under a cgroup quota of 16 CPUs of the 128-core host; a larger pool would only
+    time the throttle)."""
     import multiprocessing as mp
-    cores = min(os.cpu_count() or 1, 16)
-    n = 256 * cores
-    n = min(n, len(sb.scans))
+    phys, usable, model = host_cores()
+    cores = max(1, min(phys, usable))
+    per = 192
+    n = min(per * cores, len(sb.scans))
     chunks = np.array_split(np.arange(n), cores)
     jobs = [(sb.scans[c, -1], sb.odom0[c], sb.odom1[c], [sb.dets[i]["wp"] for i in c]) for c in chunks]
+    t_all = time.perf_counter()
+    # (i) single process, same per-sample calls
+    cpu_sample_worker(jobs[0])                              # warm-up
+    single = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        cpu_sample_worker(jobs[0])
+        single.append(len(chunks[0]) / (time.perf_counter() - t0))
+    # (ii) pool
+    rates = []
     with mp.get_context("fork").Pool(cores) as pool:
-        pool.map(cpu_sample_worker, jobs[:cores])  # warm-up
-        reps, t0 = 0, time.perf_counter()
-        while True:
+        pool.map(cpu_sample_worker, jobs)                   # warm-up: one batch
+        while len(rates) < 3 or (time.perf_counter() - t_all < budget_s and len(rates) < 9):
+            t0 = time.perf_counter()
             pool.map(cpu_sample_worker, jobs)
-            reps += 1
-            if time.perf_counter() - t0 > budget_s or reps >= 20:
-                break
-        dt = time.perf_counter() - t0
-    return {"value": n * reps / dt, "unit": "scans/s", "cores": cores, "kind": "port",
-            "sample": "%d x %d scans of the headline workload, per-sample NumPy oracle calls + collate in a "
-                      "%d-process pool (reference DataLoader shape)" % (reps, n, cores)}
+            rates.append(n / (time.perf_counter() - t0))
+    return {"value": float(np.median(rates)), "unit": "scans/s", "cores": cores, "kind": "port",
+            "single_process_scans_per_s": float(np.median(single)),
+            "host": {"model": model, "physical_cores": phys, "usable_cpus": usable},
+            "repeats": len(rates), "min": float(min(rates)), "max": float(max(rates)),
+            "sample": "%d repeats (median) of %d scans of the headline workload after one warm-up batch: per-sample "
+                      "NumPy oracle calls + collate in a %d-process pool, OMP_NUM_THREADS=1 (reference DataLoader "
+                      "shape); the single-process figure is 3 repeats of %d scans"
+                      % (len(rates), n, cores, len(chunks[0]))}
+
+
+def launch_ranks(a):
+    """--gpus N without a launcher: start N rank processes (fresh interpreters; this parent never touches HIP),
+    relay rank 0's stdout, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read().decode()
+    rcs = [p.wait() for p in procs]
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    if any(rcs):
+        sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
+        return 1
+    return 0
 
 
 def main():
     a = parse()
+    if (a.gpus > 1 or a.spawn) and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(a))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+    assert world == a.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, a.gpus)
 
     from planar_optical_flow_amd import synth
     B, N = a.batch, N_PTS
@@ -148,43 +224,8 @@ def main():
             dist.init_process_group(backend)
 
     from planar_optical_flow_amd import ops
-
-    offs, rphi, cls = sb.det_csr()
     tab = ops.phi_table(device=dev)
-    ring = []
-    for r in range(a.ring):
-        sh = (r * 509) % B  # distinct memory and distinct content per ring slot
-        scans = torch.from_numpy(np.roll(sb.scans, sh, axis=0)).to(dev)
-        o0 = torch.from_numpy(np.roll(sb.odom0, sh, axis=0)).to(dev)
-        o1 = torch.from_numpy(np.roll(sb.odom1, sh, axis=0)).to(dev)
-        counts = np.roll(np.diff(offs), sh)
-        order = np.roll(np.arange(B), sh)
-        ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
-        rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
-        det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
-        outs = {
-            "flow": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
-            "target_cls": torch.empty((B, N), dtype=torch.int64, device=dev),
-            "target_reg": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
-            "exclude_mask": torch.empty((B, N), dtype=torch.float32, device=dev),
-        }
-        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, len(rr)), dtype=torch.uint8, device=dev)
-        ring.append((scans, o0, o1, det, outs, ws))
     want = ("flow", "target_cls", "target_reg", "exclude_mask")
-
-    def step(i, phases=3):
-        scans, o0, o1, det, outs, ws = ring[i % a.ring]
-        if a.chained and phases == 3:
-            # one launch: stream batch i (its params were produced by the previous step's launch)
-            # and evaluate the params of batch i+1 on extra workgroups of the same grid
-            _, n0, n1, ndet, _, nws = ring[(i + 1) % a.ring]
-            ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws,
-                                next_batch={"odom0": n0, "odom1": n1, "dets": ndet, "workspace": nws})
-        else:
-            ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
-
-    if a.chained:
-        step(0, phases=1)  # prime the chain: params of ring slot 0
 
     def barrier():
         torch.cuda.synchronize()
@@ -192,80 +233,145 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- optional hipGraph of one trip round the ring --------------------------
-    graph = None
-    if not a.no_graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for i in range(a.ring):
-                step(i)
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            if not a.pipeline:
+    def measure(sbm):
+        """Ring of resident batches + hipGraph of one trip round it; W warm-up steps, then `repeats` timed regions
+        of EXACTLY K steps, each bracketed by barrier + synchronize, wall time maximised over ranks.
+        -> dict(wall_s [repeats], dev_ms [repeats], ring)"""
+        Bm = len(sbm.scans)
+        offs, rphi, _ = sbm.det_csr()
+        ring = []
+        for r in range(a.ring):
+            sh = (r * 509) % Bm  # distinct memory and distinct content per ring slot
+            scans = torch.from_numpy(np.roll(sbm.scans, sh, axis=0)).to(dev)
+            o0 = torch.from_numpy(np.roll(sbm.odom0, sh, axis=0)).to(dev)
+            o1 = torch.from_numpy(np.roll(sbm.odom1, sh, axis=0)).to(dev)
+            counts = np.roll(np.diff(offs), sh)
+            order = np.roll(np.arange(Bm), sh)
+            ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+            rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
+            det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
+            outs = {
+                "flow": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
+                "target_cls": torch.empty((Bm, N), dtype=torch.int64, device=dev),
+                "target_reg": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
+                "exclude_mask": torch.empty((Bm, N), dtype=torch.float32, device=dev),
+            }
+            ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, len(rr)), dtype=torch.uint8, device=dev)
+            ring.append((scans, o0, o1, det, outs, ws))
+
+        def step(i, phases=3):
+            scans, o0, o1, det, outs, ws = ring[i % a.ring]
+            if a.chained and phases == 3:
+                # one launch: stream batch i (its params were produced by the previous step's launch)
+                # and evaluate the params of batch i+1 on extra workgroups of the same grid
+                _, n0, n1, ndet, _, nws = ring[(i + 1) % a.ring]
+                ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws,
+                                    next_batch={"odom0": n0, "odom1": n1, "dets": ndet, "workspace": nws})
+            else:
+                ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
+
+        if a.chained:
+            step(0, phases=1)  # prime the chain: params of ring slot 0
+
+        # ---- optional hipGraph of one trip round the ring --------------------------
+        graph = None
+        if not a.no_graph:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
                 for i in range(a.ring):
                     step(i)
-            else:
-                # two-stream software pipeline over the independent batches of the ring: the
-                # tiny per-sample params launch of batch i+1 runs under the streaming launch of
-                # batch i (each batch has its own workspace; an event orders params(i) -> main(i))
-                main = torch.cuda.current_stream()
-                side2 = torch.cuda.Stream()
-                side2.wait_stream(main)
-                evs = []
-                with torch.cuda.stream(side2):
-                    for i in range(a.ring):
-                        step(i, phases=1)
-                        ev = torch.cuda.Event()
-                        ev.record(side2)
-                        evs.append(ev)
-                for i in range(a.ring):
-                    main.wait_event(evs[i])
-                    step(i, phases=2)
-                main.wait_stream(side2)
-
-    # K or W need not be multiples of the ring: the remainder steps get their own captured graph
-    # (an eager launch costs tens of microseconds of Python per step, several times the kernel)
-    rem_graphs = {}
-    if graph is not None and not a.pipeline:
-        for rem in sorted({a.steps % a.ring, a.warmup % a.ring} - {0}):
+            torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr):
-                for i in range(rem):
-                    step(i)
-            rem_graphs[rem] = gr
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                if not a.pipeline:
+                    for i in range(a.ring):
+                        step(i)
+                else:
+                    # two-stream software pipeline over the independent batches of the ring: the
+                    # tiny per-sample params launch of batch i+1 runs under the streaming launch of
+                    # batch i (each batch has its own workspace; an event orders params(i) -> main(i))
+                    main_s = torch.cuda.current_stream()
+                    side2 = torch.cuda.Stream()
+                    side2.wait_stream(main_s)
+                    evs = []
+                    with torch.cuda.stream(side2):
+                        for i in range(a.ring):
+                            step(i, phases=1)
+                            ev = torch.cuda.Event()
+                            ev.record(side2)
+                            evs.append(ev)
+                    for i in range(a.ring):
+                        main_s.wait_event(evs[i])
+                        step(i, phases=2)
+                    main_s.wait_stream(side2)
 
-    def run(k):
-        if graph is not None:
-            full, rem = divmod(k, a.ring)
-            for _ in range(full):
-                graph.replay()
-            if rem in rem_graphs:
-                rem_graphs[rem].replay()
+        # K or W need not be multiples of the ring: the remainder steps get their own captured graph
+        # (an eager launch costs tens of microseconds of Python per step, several times the kernel)
+        rem_graphs = {}
+        if graph is not None and not a.pipeline:
+            for rem in sorted({a.steps % a.ring, a.warmup % a.ring} - {0}):
+                torch.cuda.synchronize()
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr):
+                    for i in range(rem):
+                        step(i)
+                rem_graphs[rem] = gr
+
+        def run(k):
+            if graph is not None:
+                full, rem = divmod(k, a.ring)
+                for _ in range(full):
+                    graph.replay()
+                if rem in rem_graphs:
+                    rem_graphs[rem].replay()
+                else:
+                    for i in range(rem):
+                        step(i)
             else:
-                for i in range(rem):
+                for i in range(k):
                     step(i)
-        else:
-            for i in range(k):
-                step(i)
 
-    run(a.warmup)
-    barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run(a.steps)
-    ev1.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        run(a.warmup)
+        walls, devs = [], []
+        for _ in range(max(1, a.repeats)):
+            barrier()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            run(a.steps)
+            ev1.record()
+            barrier()
+            dt = time.perf_counter() - t0
+            if world > 1:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            walls.append(dt)
+            devs.append(ev0.elapsed_time(ev1))
+        return {"wall_s": walls, "dev_ms": devs, "ring": ring, "graph": graph is not None}
+
+    weak = measure(sb)
+    dt = float(np.median(weak["wall_s"]))
+    dev_ms = float(np.median(weak["dev_ms"]))
+    ring = weak["ring"]
+    graph = weak["graph"]
+    strong = None
+    if world > 1 and B % world == 0:
+        # SURVEY 8(e): the contiguous split of ONE 4096-scan batch, 4096 / N scans per rank and step
+        per = B // world
+        sbg = synth.make_batch(seed=2, B=B, T=2, N=N)
+        sl = slice(rank * per, (rank + 1) * per)
+        import copy
+        sbs = copy.copy(sbg)
+        sbs.scans, sbs.odom0, sbs.odom1, sbs.dets = sbg.scans[sl], sbg.odom0[sl], sbg.odom1[sl], sbg.dets[sl]
+        st = measure(sbs)
+        sdt = float(np.median(st["wall_s"]))
+        strong = {"value": B * a.steps / sdt, "unit": "scans/s", "ms_per_step": sdt / a.steps * 1e3,
+                  "scans_per_rank_per_step": per, "global_batch": B,
+                  "parallelism": "strong: one %d-scan batch split contiguously, %d scans per rank, no collective" % (B, per)}
+        del st
 
     # ---- parity of what was just computed (outside the timed region) ------------
     from oracle import ref_numpy as R
@@ -286,10 +392,12 @@ def main():
         bytes_per_scan = 4 * N + (8 + 8 + 8 + 4) * N
         launch_ms = dev_ms / a.steps
         achieved = bytes_per_scan * B / (launch_ms * 1e-3) / 1e9
-        traffic, traffic_src = pmc_traffic(("scan_preprocess_chain_kernel",) if a.chained
-                                           else ("scan_params_kernel", "scan_preprocess_kernel"))
+        kernel = "scan_flat_kernel<float>" if a.chained else "scan_params_kernel + scan_flat_kernel<float>"
+        traffic, traffic_src = pmc_traffic(("scan_flat_kernel<float>",) if a.chained
+                                           else ("scan_params_kernel", "scan_flat_kernel<float>"))
         if B != BATCH:
             traffic = None
+        walls = weak["wall_s"]
         result = {
             "metric": "scans/sec, flow-only preprocess of 450-pt synthetic scan pairs, batch 4096 per GPU "
                       "(+ flow EPE vs reference oracle)",
@@ -304,32 +412,45 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "timed_repeats": len(walls),
+            "ms_per_step_min": min(walls) / a.steps * 1e3,
+            "ms_per_step_max": max(walls) / a.steps * 1e3,
             "config": {"workload": "BASELINE configs[1]: batch %d x 450-pt scan pairs, flow-only "
                                    "(A1-A7 fused: xy, displacement flow, canonical frame, association, "
                                    "regression target, exclude mask), float32 outputs" % B,
                        "global_batch": world * B, "ring_batches": a.ring,
-                       "launch": ("eager" if graph is None else
+                       "launch": ("eager" if not graph else
                                   "hipGraph replay" + (", params launch of batch i+1 on a second stream" if a.pipeline else "")
                                   + (", chained (params of batch i+1 ride in the launch of batch i)" if a.chained else "")),
-                       "parallelism": "batch-sharded x%d, no collective" % world},
+                       "parallelism": "weak: batch-sharded x%d, %d scans per rank and step, no data-path collective" % (world, B),
+                       "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
+                       "collective_backend": (backend if world > 1 else None)},
             "epe_vs_oracle_m": epe,
-            "roofline": {"bound": "hbm", "kernel": ("scan_preprocess_chain_kernel<float,2,1>" if a.chained
-                                    else "scan_params_kernel + scan_preprocess_kernel<float,2,1>"),
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms},
+                         "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms,
+                         "launch_ms_min": min(weak["dev_ms"]) / a.steps, "launch_ms_max": max(weak["dev_ms"]) / a.steps},
         }
+        if strong is not None:
+            result["strong_scaling"] = strong
         if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line
+            result["host_fed"] = bench_host_fed(ops, sb, tab, dev)
             result["cutout"] = bench_cutout(ops, synth, tab, dev, variants=not a.no_model)
+            result["cutout_dense"] = bench_cutout_dense(ops, synth, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
             result["band_correlation"] = bench_band_corr(ops, dev)
+            result["small_kernels"] = bench_small_kernels(ops, synth, tab, dev)
             if not a.no_model:
                 result["dr_spaam_forward"] = bench_dr_spaam(ops, synth, tab, dev)
-            # PMC traffic of the same shapes (the profile run executes this very function)
-            result["cutout"]["roofline"]["traffic"] = pmc_traffic(("cutout_area_kernel", "cutout_kernel<1, 7, 1,"))[0]
-            result["spatial_attention"]["roofline"]["traffic"] = pmc_traffic(("attn_",))[0]
-            result["band_correlation"]["roofline"]["traffic"] = pmc_traffic(("band_corr_",))[0]
+            # PMC traffic of the same shapes, read from the committed counter passes (tools/collect_profiles.sh
+            # runs this very function under rocprofv3 --pmc): not measured in this run
+            for key, pref in (("cutout", ("cutout_area_kernel", "cutout_kernel<1, 7, 1,")),
+                              ("spatial_attention", ("attn_",)), ("band_correlation", ("band_corr_",))):
+                tr, src = pmc_traffic(pref)
+                result[key]["roofline"]["traffic"] = tr
+                result[key]["roofline"]["traffic_source"] = src
         if cpu is not None:
             result["cpu_baseline"] = cpu
             result["speedup_vs_cpu_baseline"] = result["value"] / cpu["value"]
@@ -337,6 +458,64 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_host_fed(ops, sb, tab, dev, steps=200):
+    """The headline step when the boundary is handed HOST buffers (never `value`): pinned host memory, H2D copies
+    of batch i+1 on a copy stream under the kernel of batch i.  PCIe-inclusive scans/s."""
+    import torch
+    B, N = sb.scans.shape[0], sb.scans.shape[2]
+    offs, rphi, _ = sb.det_csr()
+    host = {"scans": torch.from_numpy(sb.scans).pin_memory(), "o0": torch.from_numpy(sb.odom0).pin_memory(),
+            "o1": torch.from_numpy(sb.odom1).pin_memory(), "offs": torch.from_numpy(offs.astype(np.int32)).pin_memory(),
+            "rphi": torch.from_numpy(np.ascontiguousarray(rphi)).pin_memory(),
+            "cls": torch.from_numpy(np.full(len(rphi), 2, np.uint8)).pin_memory()}
+    in_bytes = sum(t.numel() * t.element_size() for t in host.values())
+    slots = []
+    for _ in range(2):
+        d = {k: torch.empty_like(v, device=dev) for k, v in host.items()}
+        outs = {"flow": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
+                "target_cls": torch.empty((B, N), dtype=torch.int64, device=dev),
+                "target_reg": torch.empty((B, N, 2), dtype=torch.float32, device=dev),
+                "exclude_mask": torch.empty((B, N), dtype=torch.float32, device=dev)}
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, len(rphi)), dtype=torch.uint8, device=dev)
+        slots.append((d, outs, ws, torch.cuda.Event(), torch.cuda.Event()))
+    copy_stream = torch.cuda.Stream()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+
+    def upload(i):
+        d, _, _, ready, free = slots[i % 2]
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(free)                 # the kernel that last read this slot has finished
+            for k, v in host.items():
+                d[k].copy_(v, non_blocking=True)
+            ready.record(copy_stream)
+
+    def compute(i):
+        d, outs, ws, ready, free = slots[i % 2]
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ready)
+        ops.scan_preprocess(d["scans"], tab, d["o0"], d["o1"], ops.DetCSR(d["offs"], d["rphi"], d["cls"]),
+                            want=want, out=outs, workspace=ws)
+        free.record(cur)
+
+    for sl in slots:
+        sl[4].record(torch.cuda.current_stream())
+    upload(0)
+    for i in range(20):
+        upload(i + 1)
+        compute(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(20, 20 + steps):
+        upload(i + 1)
+        compute(i)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    return {"host_fed_scans_per_s": B / dt, "us_per_step": dt * 1e6, "h2d_GBps": in_bytes / dt / 1e9,
+            "input_bytes_per_step": in_bytes,
+            "note": "pinned host buffers, copies of batch i+1 overlap the kernel of batch i; reported beside "
+                    "`value`, which is device-resident"}
 
 
 def _time_kernel(torch, fn, iters, warm=3):
@@ -375,6 +554,94 @@ def bench_cutout(ops, synth, tab, dev, variants=True):
             "variants_ms": {"float32_value_path": ms_f32, "float16_output": ms_f16},
             "roofline": {"bound": "hbm", "kernel": "cutout_area_kernel + cutout_kernel", "achieved": ach,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+def bench_cutout_dense(ops, synth, dev):
+    """A8 at BASELINE configs[4] shape: N = 3600 points (0.1 deg), T = 11, P = 56, float16 output."""
+    import torch
+    B, T, N, P = 64, 11, 3600, 56
+    tab = ops.phi_table(np.radians(0.1), N, device=dev)
+    sb = synth.make_batch(seed=5, B=B, T=T, N=N, angle_inc=np.radians(0.1))
+    scans = torch.from_numpy(sb.scans).to(dev)
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=P,
+              padding_val=29.99, area_mode=True)
+    out16 = torch.empty((B, N, T, P), dtype=torch.float16, device=dev)
+    out32 = torch.empty((B, N, T, P), dtype=torch.float32, device=dev)
+    ms16 = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out16, out_dtype=torch.float16, **kw), 5)
+    ms32 = _time_kernel(torch, lambda: ops.cutout(scans, tab, out=out32, **kw), 5)
+    per16 = T * N * 4 + N * T * P * 2  # 4 593 600 B (SURVEY 8(d))
+    ach = per16 * B / (ms16 * 1e-3) / 1e9
+    return {"workload": "cutout N=3600 T=11 P=56 area_mode float16 out, batch %d (BASELINE configs[4])" % B,
+            "ms_per_call": ms16, "ms_per_call_float32_out": ms32, "samples_per_s": B / (ms16 * 1e-3),
+            "roofline": {"bound": "hbm", "kernel": "cutout_area_kernel + cutout_kernel (span staging)", "achieved": ach,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None}}
+
+
+def bench_small_kernels(ops, synth, tab, dev):
+    """Timing + algorithmic bytes of the hot-path kernels that have no roofline line of their own: A11 NMS, A12 flow
+    errors, A13 segments + least squares, A16 rotated IoU (batched evaluation shape), N1 window gather, N3 segment
+    preparation.  Latency-bound helpers: `GBps` is algorithmic bytes / time, for orientation only."""
+    import torch
+    rows = {}
+    g = torch.Generator(device=dev).manual_seed(77)
+
+    def row(name, ms, nbytes, note):
+        rows[name] = {"ms_per_call": ms, "algorithmic_bytes": int(nbytes), "GBps": nbytes / (ms * 1e-3) / 1e9,
+                      "note": note}
+
+    B, N = 4096, N_PTS
+    sb = synth.make_batch(seed=21, B=B, T=1, N=N, dropout=0.0)
+    ranges = torch.from_numpy(sb.scans[:, 0].copy()).to(dev)
+    # A13: one wave per segment
+    ms = _time_kernel(torch, lambda: ops.segment_features(ranges, tab), 10)
+    _, num, _ = ops.segment_features(ranges, tab)
+    S = int(num.sum().item())
+    row("segment_kernel", ms, B * 8 * N + 128 * S,
+        "A13: %d scans, %d segments; read 4N + write 4N seg ids per scan + 128 B per segment" % (B, S))
+    nxt = torch.roll(ranges, -1, 0).contiguous()
+    ms = _time_kernel(torch, lambda: ops.segment_features_reference(ranges, tab, nxt), 10)
+    row("segment_kernel_reference_rows", ms, B * 12 * N + 120 * S,
+        "A13 in the reference's 15-column form (median selection, mean speed vs the next scan)")
+    # A11
+    Bn = 1024
+    pc = torch.rand((Bn, N), dtype=torch.float64, device=dev, generator=g)
+    pr = torch.randn((Bn, N, 2), dtype=torch.float64, device=dev, generator=g) * 0.3
+    ms = _time_kernel(torch, lambda: ops.nms_predicted_center(ranges[:Bn].contiguous(), tab, pc, pr), 10)
+    row("nms_kernel", ms, Bn * N * (4 + 8 + 16 + 16 + 8 + 4),
+        "A11: %d scans x %d points per launch (one workgroup per scan: LDS bitonic sort + greedy suppression)" % (Bn, N))
+    # A12
+    pf = torch.randn((B, N, 2), device=dev, generator=g)
+    tf = torch.randn((B, N, 2), device=dev, generator=g)
+    mk = (torch.rand((B, N), device=dev, generator=g) < 0.8).float()
+    ms = _time_kernel(torch, lambda: ops.flow_errors(pf, tf, mk), 20)
+    row("flow_errors_kernel", ms, B * N * 20, "A12: EPE / AAE sums, %d x %d points, 20 B per point" % (B, N))
+    # A16: batched evaluation shape: 256 groups x 1 prediction x <= 32 neighbour boxes
+    G, K = 256, 32
+    bx = torch.rand((G, 1, 5), device=dev, generator=g) * 2
+    qx = torch.rand((G, K, 5), device=dev, generator=g) * 2
+    bx[..., 2:4] += 0.3
+    qx[..., 2:4] += 0.3
+    kv = torch.randint(1, K + 1, (G,), device=dev, generator=g, dtype=torch.int32)
+    ms = _time_kernel(torch, lambda: ops.rotate_iou(bx, qx, k_valid=kv), 20)
+    row("rotate_iou_kernel", ms, G * (5 + 5 * K + K) * 4,
+        "A16: %d groups x 1 box x <= %d query boxes in ONE launch (the reference launches once per sample)" % (G, K))
+    # N1: window gather from the device-resident scan store
+    Sn, T = 20000, 5
+    store = torch.rand((Sn, N), device=dev, generator=g)
+    first = torch.zeros(B, dtype=torch.int32, device=dev)
+    idx = torch.randint(0, Sn, (B,), device=dev, generator=g, dtype=torch.int32)
+    ms = _time_kernel(torch, lambda: ops.gather_windows(store, first, idx, T), 20)
+    row("gather_windows_kernel", ms, B * (T + 1) * N * 8,
+        "N1: %d windows of %d + 1 rows x %d points, read + write" % (B, T, N))
+    # N3: all detections of a frame in one launch
+    Np, Sd = 4000, 64
+    pts = torch.rand((Np, 2), dtype=torch.float64, device=dev, generator=g) * 10
+    ctr = pts[torch.randint(0, Np, (Sd,), device=dev, generator=g)].contiguous()
+    ori = torch.zeros(Sd, dtype=torch.float64, device=dev)
+    ms = _time_kernel(torch, lambda: ops.segment_inputs(pts, ctr, ori), 20)
+    row("segment_inputs_kernel", ms, Np * 16 + Sd * (16 + 64 * 3 * 4),
+        "N3: %d points, %d detections: radius query + fixed-size resampling in one launch" % (Np, Sd))
+    return rows
 
 
 def bench_attention(ops, dev):

@@ -59,7 +59,12 @@ struct PreArgs {
 
 constexpr int kDetStride = 6;
 constexpr int kInline = 8;   // detections stored inline in the per-sample record
-constexpr int kRecStride = 8 + kInline * kDetStride;
+// per-sample record (doubles): [0,8) motion[7] + detection count; [8, 56) kInline detections x kDetStride;
+// then the float32 companions the flat kernel stages without arithmetic: [56, 60) = 8 floats of motion,
+// [60, 84) = kInline x 6 floats {cx, cy, Dlo, Dhi, A, pad} (the screen of screen_entry below)
+constexpr int kRecF32Mot = 8 + kInline * kDetStride;
+constexpr int kRecF32Det = kRecF32Mot + 4;
+constexpr int kRecStride = kRecF32Det + kInline * 3;
 
 // Per-sample rigid motion from the two (sin, cos) pairs the params kernel
 // evaluates on two lanes.  mot[0..3] = 2x2 matrix (row major), mot[4..5] =
@@ -176,6 +181,34 @@ __device__ __forceinline__ void det_entry(const PreArgs &a, int g, double *w)
     w[5] = cl == 0 ? a.sa0 : (cl == 1 ? a.sa1 : a.sa2);   // dist <  assoc radius <=>  s <= w[5]
 }
 
+// float32 screen of one detection against float32 squared distances s2f.  With all coordinates below
+// 100 m, |s2f - s2| <= 1e-3 + 1e-4 * s2 (s2 = the float64 squared distance the reference's decision is
+// made on; derivation in DESIGN.md section 3.1), hence
+//   s2f <= Dlo = sd (1 - 1e-4) - 1e-3   =>  s2 <= sd   (surely inside the dynamic-mask radius)
+//   s2f >  Dhi = sd (1 + 1e-4) + 1e-3   =>  s2 >  sd   (surely outside)
+//   s2f >  A   = sa (1 + 1e-4) + 1e-3   =>  s2 >  sa   (surely not an association candidate)
+// Dlo is rounded down, Dhi and A up.  A far detection gets (-inf, +inf, +inf): never decided here.
+__device__ __forceinline__ float round_dn(double v)
+{
+    float f = (float)v;
+    if ((double)f > v) f = __uint_as_float(__float_as_uint(f) + (f > 0.0f ? -1 : 1));
+    return f;
+}
+__device__ __forceinline__ float round_up(double v)
+{
+    float f = (float)v;
+    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1 : -1));
+    return f;
+}
+__device__ __forceinline__ void screen_entry(double cx, double cy, double sd, double sa, float4 *e, float *ea)
+{
+    const bool far = !(fabs(cx) + fabs(cy) < 100.0);
+    const float dlo = round_dn(sd * (1.0 - 1e-4) - 1e-3), dhi = round_up(sd * (1.0 + 1e-4) + 1e-3);
+    const float aa = round_up(sa * (1.0 + 1e-4) + 1e-3);
+    *e = make_float4((float)cx, (float)cy, far ? -INFINITY : dlo, far ? INFINITY : dhi);
+    *ea = far ? INFINITY : aa;
+}
+
 // number of params jobs of a batch: 2 per sample (the two motion angles) + kInline
 // detection slots per sample
 __host__ __device__ inline int params_job_count(int B, bool have_dets)
@@ -202,7 +235,12 @@ __device__ __forceinline__ void params_work(const PreArgs &a, int t)
         const double s_o = __shfl_xor(s, 1, 64), c_o = __shfl_xor(c, 1, 64);
         if (which == 0) {
             double *rec = a.ws_rec + (long long)b * kRecStride;
-            if (a.flow) motion_params(a.flow_kind, o0, o1, s, c, s_o, c_o, rec);
+            if (a.flow) {
+                motion_params(a.flow_kind, o0, o1, s, c, s_o, c_o, rec);
+                float *mf = reinterpret_cast<float *>(rec + kRecF32Mot);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) mf[k] = (float)rec[k];
+            }
             rec[7] = a.det_offsets ? (double)(a.det_offsets[b + 1] - a.det_offsets[b]) : 0.0;
         }
     } else if (a.det_offsets && t < nm + a.B * kInline) {
@@ -216,6 +254,11 @@ __device__ __forceinline__ void params_work(const PreArgs &a, int t)
                 double *r = a.ws_rec + (long long)b * kRecStride + 8 + idx * kDetStride;
 #pragma unroll
                 for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
+                float4 e;
+                float ea;
+                screen_entry(w[0], w[1], w[3], w[5], &e, &ea);
+                float *f = reinterpret_cast<float *>(a.ws_rec + (long long)b * kRecStride + kRecF32Det) + idx * 6;
+                f[0] = e.x; f[1] = e.y; f[2] = e.z; f[3] = e.w; f[4] = ea; f[5] = 0.0f;
             }
             if (cnt > kInline) {
                 double *r = a.ws_det + (long long)(d0 + idx) * kDetStride;
@@ -557,6 +600,329 @@ __device__ __forceinline__ void scan_main(const PreArgs &a, const int block_y)
     }
 }
 
+// ---- flat form of the streaming rows (the headline launch) ---------------------------------------
+// One workgroup chunk = 256 CONSECUTIVE POINTS OF THE FLAT [B*N] AXIS (128 lanes x 2 points), not one
+// sample.  A sample's output rows are 8N = 3600 B (N = 450): with one workgroup per sample every row
+// boundary splits a 128-byte line between two workgroups on different XCDs, and the bare I/O shape of the
+// launch runs at 4.6-4.9 TB/s; with line-aligned 2048-byte (flow / reg / cls) and 1024-byte (mask) chunks
+// the same bytes stream at 6.2-6.3 TB/s (tools/ubench/store_ceiling.hip, profiles/r2_store_*).
+// A chunk touches at most two samples (N >= 256): their records (motion, inline detections) go through
+// LDS, each lane picks its own sample's.  Crowded samples (more than kInline detections) read the rest
+// of their detections from the CSR table in the workspace (L2 hits, exact test only).
+//
+// Grid = (P, rows): chunk = x + P * y with P = N / gcd(N, 256) chunks = the period after which the chunks'
+// point-in-scan phases repeat (P * 256 points are a whole number of samples), so that sample and point
+// index follow from small per-phase numbers without a 64-bit division (which alone cost more vector
+// instructions than the flow arithmetic).  Several chunks per workgroup (records and range rows of K
+// chunks requested together) were measured and lost: 15.4 (K = 1) / 16.3 (2) / 19.8 us (4) -- the launch
+// is bound by vector-instruction issue, not by the first memory round trip (profiles/r2_headline_pmc.txt).
+constexpr int kFlatThreads = 128;
+
+struct FlatSmem {
+    double mot[2][8];               // motion[7], detection count
+    float motf[2][8];               // float32 copy of the motion (float32-output flow path)
+    double det[2][kInline][5];      // cx, cy, assoc radius, dyn s-threshold, assoc s-threshold
+    int lab[2][kInline];
+    float4 detf[2][kInline + 1];    // float32 screen: cx, cy, Dlo, Dhi  (+1: the loop reads one ahead)
+    float deta[2][kInline + 1];     // float32 screen: A
+};
+
+template <typename T>
+__device__ __forceinline__ T fma_t(T a, T b, T c);
+template <>
+__device__ __forceinline__ double fma_t<double>(double a, double b, double c) { return fma(a, b, c); }
+template <>
+__device__ __forceinline__ float fma_t<float>(float a, float b, float c) { return fmaf(a, b, c); }
+
+// apply_motion in either precision (the float64 form is the reference's operation order)
+template <typename T>
+__device__ __forceinline__ void apply_motion_t(int kind, T px, T py, T m0, T m1, T m2, T m3, T t0, T t1, T dph,
+                                               T &fx, T &fy)
+{
+    if (kind == 0) {
+        fx = fma_t<T>(py, m1, px * m0) - t0;
+        fy = fma_t<T>(py, m3, px * m2) - t1;
+    } else if (kind == 1) {
+        fx = (fma_t<T>(py, m1, px * m0) - t0) - px;
+        fy = (fma_t<T>(py, m3, px * m2) - t1) - py;
+    } else if (kind == 2) {
+        fx = -t0 - (py * -dph);
+        fy = -t1 - (px * dph);
+    } else if (kind == 3) {
+        fx = ((T)0 - m0 * py + m1) * m3;
+        fy = ((m0 * px - (T)0) + m2) * m3;
+    } else {
+        fx = fma_t<T>(py, m1, px * m0) + t0;
+        fy = fma_t<T>(py, m3, px * m2) + t1;
+    }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm, const int q, const int b,
+                                           const bool ok, const long long o2, const float2 rv,
+                                           const double2 t0v, const double2 t1v, const double *tab_cs)
+{
+    // float32 outputs: the flow is evaluated in float32 (error ~1e-7 m against the float64 reference at 25 m
+    // range; stated bar 1e-5 m in the tests, 1e-4 m in BASELINE.json).  Association, masks and regression
+    // targets are decided on the float64 values exactly as before.
+    constexpr bool kF32 = sizeof(OutT) == 4;
+    const bool want_flow = a.flow != nullptr;
+    const bool want_assoc = a.det_offsets != nullptr;
+    const float r[2] = {rv.x, rv.y};
+    const float csf[2] = {(float)t0v.x, (float)t1v.x}, snf[2] = {(float)t0v.y, (float)t1v.y};
+    F2V pxf = {r[0] * csf[0], r[1] * csf[1]}, pyf = {r[0] * snf[0], r[1] * snf[1]};
+    // float64 cos / sin are needed on the rare exact paths only: re-read there (L1 / L2 hits) instead of
+    // holding 8 registers across the whole body (the 64-register budget of 8 waves per SIMD)
+    auto cs64 = [&](int k) { return tab_cs[2 * k]; };
+    auto sn64 = [&](int k) { return tab_cs[2 * k + 1]; };
+    auto p64x = [&](int k) { return (double)r[k] * cs64(k); };
+    auto p64y = [&](int k) { return (double)r[k] * sn64(k); };
+
+    if (ok && a.xy) {
+        OutT *xy = static_cast<OutT *>(a.xy);
+        store2<OutT>(xy, 2 * o2, p64x(0), p64y(0));
+        store2<OutT>(xy, 2 * o2 + 1, p64x(1), p64y(1));
+    }
+
+    // ---- rigid-motion flow ---------------------------------------------------
+    if (want_flow) {
+        if (kF32 && a.flow_kind != 1) {   // kind 1 subtracts the point from its moved image: float64 only
+            const float4 ma = *reinterpret_cast<const float4 *>(&sm.motf[q][0]);
+            const float4 mb = *reinterpret_cast<const float4 *>(&sm.motf[q][4]);
+            float fxs[2], fys[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                float fx, fy;
+                apply_motion_t<float>(a.flow_kind, pxf[k], pyf[k], ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, fx, fy);
+                if (a.canonical) {
+                    const float gx = fmaf(csf[k], fx, -snf[k] * fy);
+                    const float gy = fmaf(snf[k], fx, csf[k] * fy);
+                    fx = gx;
+                    fy = gy;
+                }
+                fxs[k] = fx;
+                fys[k] = fy;
+            }
+            if (ok) stream_f4(reinterpret_cast<float *>(a.flow), o2, fxs[0], fys[0], fxs[1], fys[1]);
+        } else {
+            // float64 outputs (and float32 kind 1): the reference's operation order in float64
+            const double m0 = sm.mot[q][0], m1 = sm.mot[q][1], m2 = sm.mot[q][2], m3 = sm.mot[q][3];
+            const double tr0 = sm.mot[q][4], tr1 = sm.mot[q][5], dph = sm.mot[q][6];
+            OutT *fl = static_cast<OutT *>(a.flow);
+            const double cs[2] = {t0v.x, t1v.x}, sn[2] = {t0v.y, t1v.y};
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                double fx, fy;
+                apply_motion(a.flow_kind, (double)r[k] * cs[k], (double)r[k] * sn[k], m0, m1, m2, m3, tr0, tr1, dph, fx, fy);
+                if (a.canonical) {
+                    // einsum('ijk,ik->ij'): c*fx + (-s)*fy ; s*fx + c*fy, no fusion
+                    const double gx = cs[k] * fx + (-sn[k]) * fy;
+                    const double gy = sn[k] * fx + cs[k] * fy;
+                    fx = gx;
+                    fy = gy;
+                }
+                if (ok) store2<OutT>(fl, 2 * o2 + k, fx, fy);
+            }
+        }
+    }
+
+    float vmask[2], dmask[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        vmask[k] = (r[k] >= 20.0f) ? 0.0f : 1.0f;
+        dmask[k] = 1.0f;
+    }
+
+    // ---- association + dynamic mask ------------------------------------------
+    if (want_assoc) {
+        // winner so far: 1-based index; 0 = the prepended zero column.  dist - radius of a candidate is
+        // negative, so the first candidate beats the zero column without a square root; only a second
+        // candidate of the same point (two overlapping discs: rare) needs the two values, and then the
+        // incumbent's are recomputed from its index with the same operations.
+        int bidx[2] = {0, 0};
+        int dfirst = 0;
+        auto candidate = [&](int k, int j1, double s2, double ra) {
+            if (bidx[k] != 0) {
+                const double *w = (bidx[k] <= kInline) ? &sm.det[q][bidx[k] - 1][0]
+                                                       : a.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
+                const double exd = p64x(k) - w[0], eyd = p64y(k) - w[1];
+                if (!(sqrt(s2) - ra < sqrt(exd * exd + eyd * eyd) - w[2])) return;
+            }
+            bidx[k] = j1;
+        };
+        const int nd = ok ? (int)sm.mot[q][7] : 0;
+        const int n_in = min(nd, kInline);
+        bool far[2], inside[2] = {false, false}, all_out[2] = {true, true};
+#pragma unroll
+        for (int k = 0; k < 2; ++k) far[k] = !(fabsf(pxf[k]) + fabsf(pyf[k]) < 100.0f);   // NaN -> exact
+        float4 fnext = sm.detf[q][0];
+        float anext = sm.deta[q][0];
+        for (int j = 0; j < n_in; ++j) {
+            const float4 f = fnext;
+            const float fa = anext;
+            fnext = sm.detf[q][j + 1];
+            anext = sm.deta[q][j + 1];
+            const F2V cx2 = {f.x, f.x}, cy2 = {f.y, f.y};
+            const F2V ex = pxf - cx2, ey = pyf - cy2;
+            F2V s2f = ey * ey;
+            s2f = __builtin_elementwise_fma(ex, ex, s2f);
+            bool need = false;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                inside[k] |= s2f[k] <= f.z;
+                all_out[k] &= s2f[k] > f.w;
+                need |= (s2f[k] <= fa) || far[k];
+            }
+            if (need) {
+                const double cx = sm.det[q][j][0], cy = sm.det[q][j][1], sa = sm.det[q][j][4];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (!((s2f[k] <= fa) || far[k])) continue;
+                    const double exd = p64x(k) - cx, eyd = p64y(k) - cy;
+                    const double s2 = exd * exd + eyd * eyd;   // cdist: (dx*dx) + (dy*dy), no fusion
+                    if (s2 <= sa) candidate(k, j + 1, s2, sm.det[q][j][2]);   // dist < assoc radius
+                }
+            }
+        }
+        // dynamic mask: decided by the screen unless a point sits within the error band of a threshold
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (inside[k] && !far[k]) {
+                dmask[k] = 0.0f;
+            } else if (far[k] || !all_out[k]) {
+                const double pxd = p64x(k), pyd = p64y(k);
+                for (int j = 0; j < n_in; ++j) {
+                    const double exd = pxd - sm.det[q][j][0], eyd = pyd - sm.det[q][j][1];
+                    if (exd * exd + eyd * eyd <= sm.det[q][j][3]) dmask[k] = 0.0f;   // dist <= dyn radius
+                }
+            }
+        }
+        if (nd > kInline) {
+            // crowded sample: detections kInline.. from the CSR table (every lane of the sample reads the
+            // same rows: L1 / L2 hits), exact test only
+            dfirst = a.det_offsets[b];
+            for (int j = kInline; j < nd; ++j) {
+                const double *w = a.ws_det + (long long)(dfirst + j) * kDetStride;
+                const double cx = w[0], cy = w[1], ra = w[2], sd = w[3], sa = w[5];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const double exd = p64x(k) - cx, eyd = p64y(k) - cy;
+                    const double s2 = exd * exd + eyd * eyd;
+                    if (s2 <= sd) dmask[k] = 0.0f;
+                    if (s2 <= sa) candidate(k, j + 1, s2, ra);
+                }
+            }
+        }
+        if (ok) {
+            long long cls[2];
+            float gx[2], gy[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                cls[k] = 0;
+                gx[k] = gy[k] = 0.0f;
+                if (bidx[k] > 0) {
+                    // winner's centre and label.  global_to_canonical via the angle-difference identity:
+                    // sin(dp-phi)*dr = cy*cos(phi) - cx*sin(phi)
+                    double wx, wy;
+                    if (bidx[k] <= kInline) {
+                        wx = sm.det[q][bidx[k] - 1][0];
+                        wy = sm.det[q][bidx[k] - 1][1];
+                        cls[k] = sm.lab[q][bidx[k] - 1];
+                    } else {
+                        const double *w = a.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
+                        wx = w[0];
+                        wy = w[1];
+                        cls[k] = (long long)w[4];
+                    }
+                    const double c = cs64(k), sn_ = sn64(k);
+                    gx[k] = (float)(wy * c - wx * sn_);
+                    gy[k] = (float)((wx * c + wy * sn_) - (double)r[k]);
+                }
+            }
+            if (a.closest) stream_ll2(reinterpret_cast<long long *>(a.closest), o2, bidx[0], bidx[1]);
+            if (a.target_cls) stream_ll2(reinterpret_cast<long long *>(a.target_cls), o2, cls[0], cls[1]);
+            if (a.target_reg) stream_f4(a.target_reg, o2, gx[0], gy[0], gx[1], gy[1]);
+        }
+    }
+
+    if (ok) {
+        if (a.dyn_mask) stream_f2(a.dyn_mask, o2, dmask[0], dmask[1]);
+        if (a.valid_mask) stream_f2(a.valid_mask, o2, vmask[0], vmask[1]);
+        if (a.exclude_mask) stream_f2(a.exclude_mask, o2, dmask[0] * vmask[0], dmask[1] * vmask[1]);
+    }
+}
+
+template <typename OutT>
+__device__ __forceinline__ void scan_flat(const PreArgs &a, const int phase, const int row, const int period,
+                                          const float inv_half_n)
+{
+    __shared__ FlatSmem sm;
+
+    const int tid = threadIdx.x;
+    const int N = a.N, halfN = N >> 1;
+    // chunk = phase + period * row.  period * 256 points are a whole number of samples (sstep), so the sample
+    // and the point-in-scan index come from the phase alone -- no wide division: x < 2^24 is exact in float32
+    const unsigned x = (unsigned)phase * kFlatThreads;            // pairs since the row's first sample
+    unsigned sp = (unsigned)((float)x * inv_half_n);
+    if (sp * (unsigned)halfN > x) --sp;
+    else if ((sp + 1) * (unsigned)halfN <= x) ++sp;
+    const int sstep = period * kFlatThreads / halfN;              // samples per row of chunks
+    const int sA = row * sstep + (int)sp;                         // workgroup-uniform
+    int local = (int)(x - sp * (unsigned)halfN) + tid;
+    const int q = local >= halfN ? 1 : 0;                         // kFlatThreads <= halfN: at most one wrap
+    local -= q ? halfN : 0;
+    const int i0 = 2 * local;
+    const int b = sA + q;
+    const bool ok = b < a.B;
+    const long long o2 = (long long)b * halfN + local;            // flat pair index: point o = 2 * o2
+
+    // ---- issue every load first ---------------------------------------------
+    // unconditional (clamped) load: a load inside `if (ok)` makes the compiler wait for it at the end of the
+    // branch, i.e. BEFORE the table and record loads are even issued -- two memory round trips instead of one
+    const float2 rv = *reinterpret_cast<const float2 *>(a.ranges + (long long)min(b, a.B - 1) * a.sample_stride + i0);
+    const double2 t0v = *reinterpret_cast<const double2 *>(a.tab + N + 2 * i0);
+    const double2 t1v = *reinterpret_cast<const double2 *>(a.tab + N + 2 * i0 + 2);
+    if (a.flow != nullptr || a.det_offsets != nullptr) {
+        // records -> LDS: a pure copy (the float32 motion and the detection screens were written by the
+        // params job that produced the record)
+        if (tid < 16) {
+            const int sq = tid >> 3, c = tid & 7;
+            const int bs = min(sA + sq, a.B - 1);
+            const double *rec = a.ws_rec + (long long)bs * kRecStride;
+            sm.mot[sq][c] = rec[c];
+            sm.motf[sq][c] = reinterpret_cast<const float *>(rec + kRecF32Mot)[c];
+        } else if (a.det_offsets != nullptr && tid < 16 + 2 * kInline) {
+            const int w_ = tid - 16, sq = w_ / kInline, d = w_ - sq * kInline;
+            const int bs = min(sA + sq, a.B - 1);
+            const double *rec = a.ws_rec + (long long)bs * kRecStride;
+            const double *w = rec + 8 + d * kDetStride;
+            const float *f = reinterpret_cast<const float *>(rec + kRecF32Det) + d * 6;
+            sm.det[sq][d][0] = w[0];
+            sm.det[sq][d][1] = w[1];
+            sm.det[sq][d][2] = w[2];
+            sm.det[sq][d][3] = w[3];
+            sm.det[sq][d][4] = w[5];
+            sm.lab[sq][d] = (int)w[4];
+            sm.detf[sq][d] = make_float4(f[0], f[1], f[2], f[3]);
+            sm.deta[sq][d] = f[4];
+        }
+        __syncthreads();
+    }
+    flat_chunk<OutT>(a, sm, q, b, ok, o2, rv, t0v, t1v, a.tab + N + 2 * i0);
+}
+
+// grid (period, rows + extra): rows [0, main_rows) stream the current batch, the rest run the params jobs of
+// the NEXT batch (chained form; params rows last, see scan_preprocess_chain_kernel)
+template <typename OutT>
+__global__ __launch_bounds__(kFlatThreads, 8) void scan_flat_kernel(PreArgs a, PreArgs nx, int main_rows, float inv_half_n)
+{
+    if ((int)blockIdx.y >= main_rows) {
+        params_work(nx, (((int)blockIdx.y - main_rows) * (int)gridDim.x + (int)blockIdx.x) * kFlatThreads + threadIdx.x);
+        return;
+    }
+    scan_flat<OutT>(a, blockIdx.x, blockIdx.y, gridDim.x, inv_half_n);
+}
+
 // ---- A4 stand-alone rotation ------------------------------------------------
 template <typename T>
 __global__ void rotate_flow_kernel(const T *in, T *out, const double *tab, long long total, int N,
@@ -832,7 +1198,20 @@ int launch_preprocess(const float *ranges, long long sample_stride, int B, int N
     // One sample per workgroup.  (Two samples per workgroup share the table loads and were
     // faster with ordinary stores; with streaming stores one is: 15.4 vs 17.9 us per step.)
     bool chained = false;
-    if (vec2) {
+    const long long flat_chunks = ((long long)B * (N / 2) + kFlatThreads - 1) / kFlatThreads;
+    int g = N, h = 2 * kFlatThreads;
+    while (h) { const int t = g % h; g = h; h = t; }
+    const int period = N / g;                                        // chunks after which the point phases repeat
+    const long long rows = (flat_chunks + period - 1) / period;
+    const int extra_rows = (int)(((long long)next_jobs + (long long)period * kFlatThreads - 1) / ((long long)period * kFlatThreads));
+    if (vec2 && N >= 2 * kFlatThreads && (long long)period * kFlatThreads < (1 << 24) && rows + extra_rows <= 65535) {
+        // flat form: line-aligned output chunks per workgroup (see scan_flat)
+        dim3 grid(period, (unsigned)(rows + extra_rows));
+        const float inv = 1.0f / (float)(N / 2);
+        if (out_f64) scan_flat_kernel<double><<<grid, kFlatThreads, 0, s>>>(a, nx, (int)rows, inv);
+        else scan_flat_kernel<float><<<grid, kFlatThreads, 0, s>>>(a, nx, (int)rows, inv);
+        chained = true;
+    } else if (vec2) {
         dim3 grid((N / 2 + kThreads - 1) / kThreads, B);
         const int extra = (next_jobs + kThreads - 1) / kThreads;
         if (extra > 0 && B + extra <= 65535) {

@@ -711,23 +711,81 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
         tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
 
 
-def test_bench_two_ranks_share_the_gpu():
-    """The driver's N > 1 launch line, rehearsed with two ranks on the one GPU (gloo instead of RCCL, which
-    needs a device per rank): barriers, max-over-ranks timing and the single JSON line of rank 0."""
+def _bench_line(args, env_extra, timeout=400, launcher=False):
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, POF_BENCH_SHARE_GPU="1", POF_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29517", os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "40",
-           "--warmup", "8"]
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=repo, timeout=300)
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable]
+    if launcher:
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29517"]
+    cmd += [os.path.join(repo, "bench.py")] + args
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=repo, timeout=timeout)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                     # rank 0 only
-    d = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def _check_two_rank_line(d):
     assert d["n_gpus"] == 2 and d["steps"] == 40 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["global_batch"] == 2 * 4096 and d["epe_vs_oracle_m"] < 1e-5
+    assert d["timed_repeats"] == 3 and d["ms_per_step_min"] <= d["ms_per_step"] <= d["ms_per_step_max"]
     assert "cpu_baseline" not in d and "cutout" not in d       # N = 1 only
+    st = d["strong_scaling"]                                   # one 4096-scan batch cut in two
+    assert st["scans_per_rank_per_step"] == 2048 and st["global_batch"] == 4096 and st["value"] > 0
+    assert d["config"]["collective_backend"] == "gloo" and d["config"]["rccl_ranks"] is None
+
+
+def test_bench_plain_command_line_starts_its_own_ranks():
+    """`python bench.py --gpus 2` -- the plain command line, no launcher, no WORLD_SIZE: the parent starts two
+    fresh rank processes itself and relays rank 0's line.  Rehearsed with both ranks on the one GPU (gloo
+    instead of RCCL, which needs a device per rank)."""
+    d = _bench_line(["--gpus", "2", "--steps", "40", "--warmup", "8", "--repeats", "3"],
+                    {"POF_BENCH_SHARE_GPU": "1", "POF_BENCH_BACKEND": "gloo"})
+    _check_two_rank_line(d)
+
+
+def test_bench_two_ranks_under_torch_distributed_run():
+    """The driver's N > 1 launch line (torch.distributed.run): ranks from the environment, same line."""
+    d = _bench_line(["--gpus", "2", "--steps", "40", "--warmup", "8", "--repeats", "3"],
+                    {"POF_BENCH_SHARE_GPU": "1", "POF_BENCH_BACKEND": "gloo"}, launcher=True)
+    _check_two_rank_line(d)
+
+
+def test_bench_launcher_path_equals_direct_path_at_one_gpu():
+    """--gpus 1 through the rank launcher (--spawn) against the direct path: same line, same rate (medians of 5
+    timed regions; 10 % covers the run-to-run spread of a 15 us launch on one box)."""
+    args = ["--steps", "400", "--warmup", "40", "--no-cpu-baseline", "--no-extra"]
+    direct = _bench_line(args, {})
+    spawned = _bench_line(args + ["--spawn"], {})
+    assert spawned["n_gpus"] == direct["n_gpus"] == 1
+    assert abs(spawned["value"] / direct["value"] - 1.0) < 0.10, (spawned["value"], direct["value"])
+
+
+def test_bench_single_gpu_line_and_world_size_check():
+    """--gpus 1: roofline / cpu_baseline / host-fed objects present and consistent; a WORLD_SIZE that disagrees
+    with --gpus is refused instead of silently measuring one GPU."""
+    import os, subprocess, sys
+    d = _bench_line(["--steps", "80", "--warmup", "8", "--repeats", "3", "--no-model"], {})
+    assert d["n_gpus"] == 1 and "strong_scaling" not in d
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    assert abs(rf["achieved"] - rf["bytes_per_launch"] / (rf["launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["launch_ms"] <= d["ms_per_step"] * 1.02            # kernel time never above step time
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["repeats"] >= 3 and cb["cores"] == min(cb["host"]["physical_cores"], cb["host"]["usable_cpus"])
+    assert cb["single_process_scans_per_s"] > 0 and cb["min"] <= cb["value"] <= cb["max"]
+    assert 0 < d["host_fed"]["host_fed_scans_per_s"] < d["value"]
+    assert set(d["small_kernels"]) >= {"segment_kernel", "nms_kernel", "rotate_iou_kernel", "flow_errors_kernel",
+                                       "gather_windows_kernel", "segment_inputs_kernel"}
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "8"],
+                       capture_output=True, text=True, env=env, cwd=repo, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
 
 
 def test_box_head_gpu_forward_equals_reference(golden):
