@@ -320,11 +320,14 @@ def cutout(
 # --------------------------------------------------------------------------
 
 
-def nms_predicted_center(scan, phi, pred_cls, pred_reg, min_dist=0.5):
+def nms_predicted_center(scan, phi, pred_cls, pred_reg, min_dist=0.5, stable_ties=False):
+    """stable_ties=False: the reference's np.argsort(...)[::-1] (ties in NumPy's introsort order, i.e. unpinned);
+    stable_ties=True: equal scores by descending point index (argsort(kind="stable")[::-1]), the total order the
+    HIP kernel defines for the saturated scores of a deployed detector."""
     assert pred_cls.shape[1] == 1
     r, p = canonical_to_det(scan, phi, pred_reg[:, 0], pred_reg[:, 1])
     xs, ys = polar_to_xy(r, p)
-    order = np.argsort(pred_cls[:, 0])[::-1]
+    order = np.argsort(pred_cls[:, 0], kind="stable" if stable_ties else None)[::-1]
     xs, ys = xs[order], ys[order]
     scores = pred_cls[order]
     n = len(scan)

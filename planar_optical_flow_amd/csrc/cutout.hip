@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) void cutout_area_kernel(CutArgs a)
 struct WinTable {
     double *a0, *step, *dd, *step_a;
     float *ylo, *yhi, *ypad;      // output-space clip bounds and the padded output value
-    int *isarea, *out_off, *row_off, *alist;
+    int *isarea, *out_off, *row_off, *alist, *krange;
     __device__ WinTable(unsigned char *base, int cap)
     {
         a0 = reinterpret_cast<double *>(base);
@@ -133,10 +133,11 @@ struct WinTable {
         out_off = isarea + cap;
         row_off = out_off + cap;
         alist = row_off + cap;
+        krange = alist + cap;
     }
 };
-// bytes per entry (4 doubles + 3 floats + 4 ints), rounded so the rows that follow stay 16-byte aligned
-__host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 60 + 15) & ~(size_t)15; }
+// bytes per entry (4 doubles + 3 floats + 5 ints), rounded so the rows that follow stay 16-byte aligned
+__host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap * 64 + 15) & ~(size_t)15; }
 
 // The tail of the reference's arithmetic, ct -> output: optional centring and scaling in
 // float64, then the float32 cast.  It is monotone in ct, so np.clip(ct, lo, hi) before it
@@ -237,11 +238,36 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
         wt.out_off[p] = a.fixed ? p * P : jj * T * P;   // (jj*T + t)*P, t = 0 when !fixed
         wt.row_off[p] = a.fixed ? t : 0;                // first scan row this window reads
+        // The fractional index is monotone in k (every rounding of its sequence is), so the samples that fall
+        // inside the field of view, 0 <= idx <= N-1, are one interval [klo, khi] of k: found here once per
+        // window (exact evaluations at the ends; a short exact search only for windows that stick out of the
+        // field of view), so that phase B needs no per-sample range test for the windows that lie inside.
+        const double i_first = frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
+        const double i_last = frac_index(w.a0, step, (double)(P - 1), phi0, dphi, rdphi);
+        int klo = 0, khi = P - 1;
+        {
+            const double nm1_ = (double)(N - 1);
+            auto neg = [](double x) { return __double2hiint(x) < 0; };
+            if (neg(i_first) || i_last > nm1_) {
+                const double c1 = step * rdphi, c0 = (w.a0 - phi0) * rdphi;
+                if (neg(i_first)) {
+                    const double e = ceil(-c0 / c1);
+                    klo = (e >= 0.0 && e <= (double)P) ? (int)e : (e > (double)P ? P : 0);
+                    while (klo > 0 && !neg(frac_index(w.a0, step, (double)(klo - 1), phi0, dphi, rdphi))) --klo;
+                    while (klo < P && neg(frac_index(w.a0, step, (double)klo, phi0, dphi, rdphi))) ++klo;
+                }
+                if (i_last > nm1_) {
+                    const double e = floor((nm1_ - c0) / c1);
+                    khi = (e >= -1.0 && e <= (double)(P - 1)) ? (int)e : (e > (double)(P - 1) ? P - 1 : -1);
+                    while (khi < P - 1 && !(frac_index(w.a0, step, (double)(khi + 1), phi0, dphi, rdphi) > nm1_)) ++khi;
+                    while (khi >= 0 && frac_index(w.a0, step, (double)khi, phi0, dphi, rdphi) > nm1_) --khi;
+                }
+            }
+        }
+        wt.krange[p] = klo | (khi << 16);
         if (LDSMODE == 2) {
             // index range touched by this window (lerp: floor(idx), +1; area samples stay in
             // the same angular span; one extra element each side for the float32 step rounding)
-            const double i_first = frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
-            const double i_last = frac_index(w.a0, step, (double)(P - 1), phi0, dphi, rdphi);
             const int lo_w = min(max((int)floor(i_first) - 1, 0), N - 1);
             const int hi_w = min(max((int)floor(i_last) + 2, 0), N - 1);
             atomicMin(&s_span_lo, lo_w);
@@ -250,8 +276,7 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         int isarea = 0;
         double step_a = 0.0;
         if (s_area > 0) {
-            double width = frac_index(w.a0, step, (double)(P - 1), phi0, dphi, rdphi) -
-                           frac_index(w.a0, step, 0.0, phi0, dphi, rdphi);
+            const double width = i_last - i_first;
             isarea = width > (double)P;
             step_a = (double)__fdiv_rn(2.0f * w.ha, (float)(PA - 1));
         }
@@ -307,22 +332,29 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     // One (window, 4-sample group): AREA = false is the interpolation path, AREA = true the
     // area-sampling path of windows that cover more than P raw points.  Two instantiations
     // keep every area-only instruction (and its selects) out of the common loop.
-    auto group = [&](auto area_tag, const int p, const int k0) {
+    auto group = [&](auto area_tag, auto full_tag, const int p, const int k0) {
         constexpr bool AREA = decltype(area_tag)::value;
+        // FULL: all KV samples of this lane lie inside the field of view (phase A's k interval): no range
+        // test, no index clamp, no padding select
+        constexpr bool FULL = decltype(full_tag)::value;
         const double a0 = wt.a0[p], step = wt.step[p];
         const double dd = wt.dd[p];
         const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
+        const int kr = FULL ? 0 : wt.krange[p];
+        const int klo = kr & 0xffff, khi = kr >> 16;
         const double kd0 = (double)k0;
         using RatioT = typename std::conditional<VMODE == 2, float, double>::type;
         RatioT ratio[KV];
         int lo[KV];
         bool outb[KV];
+#pragma unroll
+        for (int u = 0; u < KV; ++u) outb[u] = FULL ? false : (k0 + u < klo || k0 + u > khi);
         if (VMODE == 2) {
             // Approximate-then-verify index: idx' = c0 + k*c1 with c0 = (a0-phi0)/dphi, c1 = step/dphi
-            // is within 3e-12 of the reference's rounding sequence (N <= 4096), so floor, fract and
-            // the range tests agree with it unless idx' is within 1e-6 of an integer; only those
-            // lanes (2e-6 of all samples) run the exact sequence.  One float64 FMA instead of five.
+            // is within 3e-12 of the reference's rounding sequence (N <= 4096), so floor and fract
+            // agree with it unless idx' is within 1e-6 of an integer; only those lanes (2e-6 of all
+            // samples) run the exact sequence.  One float64 FMA instead of five.
             const double c1 = step * rdphi;
             const double base = fma(kd0, c1, (a0 - phi0) * rdphi);
 #pragma unroll
@@ -330,26 +362,21 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 const double idx = fma((double)u, c1, base);
                 float rf = (float)__builtin_amdgcn_fract(idx);
                 int l = (int)idx;
-                bool ob = (__double2hiint(idx) < 0) || (l >= N - 1);
                 if (!(rf >= 1e-6f && rf <= 1.0f - 1e-6f)) {   // near an integer (or NaN): exact sequence
                     const double ie = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
-                    ob = (__double2hiint(ie) < 0) || (ie > nm1);
                     l = (int)ie;
                     rf = (float)__builtin_amdgcn_fract(ie);
                 }
-                outb[u] = ob;
-                lo[u] = min(max(l, 0), N - 1);
+                lo[u] = FULL ? l : min(max(l, 0), N - 1);
                 ratio[u] = rf;
             }
         } else {
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
                 const double idx = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
-                // idx < 0 via the sign bit (idx is never -0: RN(x - x) = +0), idx > N-1 compared
-                outb[u] = (__double2hiint(idx) < 0) || (idx > nm1);
                 // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
                 // range the value is replaced by the padding, only the address must stay legal
-                lo[u] = min(max((int)idx, 0), N - 1);
+                lo[u] = FULL ? (int)idx : min(max((int)idx, 0), N - 1);
                 ratio[u] = __builtin_amdgcn_fract(idx);
             }
         }
@@ -410,8 +437,11 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                         // both taps with one LDS access (adjacent words).  At lo = N-1 the second tap is the
                         // next row's first element (or the zeroed pad word after the last row): only
                         // idx == N-1 exactly gets there in range, with ratio 0, and 0 * finite = 0
-                        vlo = s_rows[roff + lo[u]];
-                        vhi = s_rows[roff + lo[u] + 1];
+                        // byte address = (lo << 2) + row base: one v_lshl_add_u32, both taps from one ds_read2_b32
+                        const float *tap = reinterpret_cast<const float *>(
+                            reinterpret_cast<const unsigned char *>(s_rows) + ((lo[u] << 2) + (roff << 2)));
+                        vlo = tap[0];
+                        vhi = tap[1];
                     } else {
                         vlo = fetch(roff + lo[u]);
                         vhi = fetch(roff + min(lo[u] + 1, N - 1));
@@ -426,9 +456,10 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                         y = finish_value<VMODE>(a, ct, dd);
                     }
                 }
-                // np.clip pushed through the monotone tail, then the out-of-FOV padding
-                y = fminf(fmaxf(y, ylo), yhi);
-                res[u] = outb[u] ? ypad : y;
+                // np.clip pushed through the monotone tail (one v_med3_f32; ylo <= yhi), then the
+                // out-of-FOV padding
+                y = __builtin_amdgcn_fmed3f(y, ylo, yhi);
+                res[u] = (!FULL && outb[u]) ? ypad : y;
             }
             const int o_el = out_off + tt * P + k0;
             if (out_tile16) {   // uniform: float16 storage, 2 bytes per sample (8 samples = one 16-byte store)
@@ -460,17 +491,27 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
     };
 
-    // B1: every window that is not area-sampled
-    for (int g = threadIdx.x; g < total; g += kThreads) {
-        const int p = (P4 > 0) ? g / P4 : g / per_win;
-        if (wt.isarea[p]) continue;
-        group(std::false_type{}, p, (g - p * per_win) * KV);
+    // B1: every window that is not area-sampled.  The lanes of a wave whose samples all lie inside the field of
+    // view (all but the windows at the two ends of the scan) take the variant without range tests.
+    for (int g0 = 0; g0 < total; g0 += kThreads) {
+        const int g = g0 + threadIdx.x;
+        const bool act = g < total;
+        const int p = act ? ((P4 > 0) ? g / P4 : g / per_win) : 0;
+        const int k0 = (g - p * per_win) * KV;
+        const bool work = act && !wt.isarea[p];
+        const int kr = wt.krange[p];
+        const bool full = (kr & 0xffff) <= k0 && k0 + KV - 1 <= (kr >> 16);
+        if (__all(full || !work)) {
+            if (work) group(std::false_type{}, std::true_type{}, p, k0);
+        } else {
+            if (work) group(std::false_type{}, std::false_type{}, p, k0);
+        }
     }
     // B2: the area-sampled windows, from the list phase A compacted
     const int n_area = s_area > 0 ? s_acount : 0;
     for (int g = threadIdx.x; g < n_area * per_win; g += kThreads) {
         const int q = (P4 > 0) ? g / P4 : g / per_win;
-        group(std::true_type{}, wt.alist[q], (g - q * per_win) * KV);
+        group(std::true_type{}, std::false_type{}, wt.alist[q], (g - q * per_win) * KV);
     }
 }
 
@@ -546,6 +587,7 @@ int cutout_launch(const float *scans, int B, int T, int N, const double *tab, in
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
         clear_area_kernel<<<(B + 255) / 256, 256, 0, s>>>(workspace, B);
+        POF_CHECK_LAUNCH();
         const int windows = (fixed ? T : 1) * a.Ns;
         int chunks = (windows + kThreads - 1) / kThreads;
         // enough workgroups to fill the chip at small B, at most one window per lane

@@ -1,8 +1,10 @@
 // A11: nms_predicted_center (src/utils/utils.py:535-571), one workgroup per scan.
 //
 //   1. regression offsets -> detection centres (canonical_to_global + rphi_to_xy)
-//   2. sort by descending score (bitonic, in LDS; scores must be distinct: the
-//      reference's argsort()[::-1] is unstable on ties)
+//   2. sort by descending score (bitonic, in LDS).  The order is total: equal scores (a saturated
+//      sigmoid gives many exact 1.0s in deployment) are visited by DESCENDING point index, i.e. like
+//      np.argsort(kind="stable")[::-1]; the reference's argsort()[::-1] leaves ties to NumPy's
+//      introsort, so only distinct scores are comparable with it bit for bit
 //   3. greedy suppression in score order: a kept centre labels every centre
 //      closer than min_dist with its instance id (later ids overwrite earlier
 //      ones, as in the reference) and suppresses it
@@ -62,14 +64,17 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(NmsArgs a)
                 if (l > i) {
                     const bool desc = (i & k) == 0;
                     const double ki = s_key[i], kl = s_key[l];
-                    // padding (-inf, ord -1) stays behind real entries
-                    const bool swap = desc ? (ki < kl) : (ki > kl);
+                    const int oi = s_ord[i], ol = s_ord[l];
+                    // total order: (score, point index) descending; padding (-inf, ord -1) stays behind
+                    // real entries
+                    const bool l_first = (kl > ki) || (kl == ki && ol > oi);
+                    const bool i_first = (ki > kl) || (ki == kl && oi > ol);
+                    const bool swap = desc ? l_first : i_first;
                     if (swap) {
                         s_key[i] = kl;
                         s_key[l] = ki;
-                        const int t = s_ord[i];
-                        s_ord[i] = s_ord[l];
-                        s_ord[l] = t;
+                        s_ord[i] = ol;
+                        s_ord[l] = oi;
                     }
                 }
             }

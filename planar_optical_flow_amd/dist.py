@@ -70,8 +70,10 @@ class GradientAllReduce:
         dev = self.params[0].device if self.params else torch.device("cpu")
         self.bucket = torch.zeros(n, dtype=torch.float32, device=dev)
 
-    def __call__(self):
-        if not is_distributed():
+    def __call__(self, force=False):
+        """force=True also runs the (then trivial) collective in a one-rank group: the world-size-1 RCCL smoke
+        test drives the device path that way."""
+        if not (is_distributed() or (force and dist.is_available() and dist.is_initialized())):
             return
         off = 0
         for p in self.params:
@@ -91,6 +93,85 @@ class GradientAllReduce:
             else:
                 p.grad.copy_(self.bucket[off:off + n].reshape(p.shape))
             off += n
+
+
+def any_rank(flag, device=None):
+    """True on every rank as soon as `flag` is true on one: the stop flag of the training loop (a SIGTERM may
+    reach only some ranks; without agreement the others would block in the next gradient all-reduce)."""
+    if not is_distributed():
+        return bool(flag)
+    use_dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=use_dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0)
+
+
+class _SyncBatchNormFn(torch.autograd.Function):
+    """BatchNorm over the GLOBAL batch: per-channel sum / sum of squares (2C + 1 numbers, float64) are all-reduced
+    in the forward, per-channel sum(dy) / sum(dy * xhat) (2C numbers) in the backward.  Works on any backend
+    (gloo on CPU for the tests, RCCL on the GPUs)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        C = x.shape[1]
+        dims = [d for d in range(x.dim()) if d != 1]
+        xd = x.double()
+        stat = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
+        stat[:C] = xd.sum(dims)
+        stat[C:2 * C] = (xd * xd).sum(dims)
+        stat[2 * C] = x.numel() // C
+        dist.all_reduce(stat, op=dist.ReduceOp.SUM)
+        n = stat[2 * C]
+        mean = stat[:C] / n
+        var = torch.clamp(stat[C:2 * C] / n - mean * mean, min=0.0)            # biased, as BatchNorm normalises
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(momentum * mean.to(running_mean.dtype))
+                running_var.mul_(1 - momentum).add_(momentum * (var * n / torch.clamp(n - 1, min=1.0)).to(running_var.dtype))
+        shape = [1, C] + [1] * (x.dim() - 2)
+        xhat = ((xd - mean.view(shape)) * invstd.view(shape)).to(x.dtype)
+        ctx.save_for_backward(xhat, weight, invstd.to(x.dtype))
+        ctx.n = float(n.item())
+        return xhat * weight.view(shape) + bias.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        xhat, weight, invstd = ctx.saved_tensors
+        C = xhat.shape[1]
+        dims = [d for d in range(xhat.dim()) if d != 1]
+        shape = [1, C] + [1] * (xhat.dim() - 2)
+        red = torch.empty(2 * C, dtype=torch.float64, device=dy.device)
+        red[:C] = dy.double().sum(dims)
+        red[C:] = (dy.double() * xhat.double()).sum(dims)
+        d_bias, d_weight = red[:C].to(dy.dtype).clone(), red[C:].to(dy.dtype).clone()   # local: the gradient
+        dist.all_reduce(red, op=dist.ReduceOp.SUM)                                       # bucket averages them
+        s1, s2 = (red[:C] / ctx.n).to(dy.dtype), (red[C:] / ctx.n).to(dy.dtype)
+        dx = (weight * invstd).view(shape) * (dy - s1.view(shape) - xhat * s2.view(shape))
+        return dx, d_weight, d_bias, None, None, None, None
+
+
+class SyncBatchNorm1d(torch.nn.BatchNorm1d):
+    """nn.BatchNorm1d whose training-mode statistics span all ranks (same parameters, buffers and state-dict
+    keys).  Eval mode and un-initialised process groups fall through to the stock module."""
+
+    def forward(self, x):
+        if not (self.training and dist.is_available() and dist.is_initialized()) or not self.track_running_stats:
+            return super().forward(x)
+        if self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        momentum = self.momentum if self.momentum is not None else 1.0 / float(self.num_batches_tracked)
+        return _SyncBatchNormFn.apply(x, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                      momentum)
+
+
+def convert_sync_batchnorm(module):
+    """Swap every nn.BatchNorm1d of `module` for SyncBatchNorm1d IN PLACE (the class of the existing objects is
+    changed, so parameters, buffers, optimizer references and checkpoint keys stay what they were)."""
+    for m in module.modules():
+        if type(m) is torch.nn.BatchNorm1d:
+            m.__class__ = SyncBatchNorm1d
+    return module
 
 
 def broadcast_parameters(model, src=0):

@@ -2,7 +2,12 @@
 gradient exchange added: between ``loss.backward()`` and gradient clipping the
 gradients are averaged over all ranks through one flat RCCL all-reduce
 (planar_optical_flow_amd.dist.GradientAllReduce), so clipping and Adam see the
-global-batch gradient exactly as on one GPU."""
+global-batch gradient exactly as on one GPU.  Under torch.distributed the BatchNorm
+layers take their training statistics over the global batch (dist.SyncBatchNorm1d;
+cfg key ``sync_bn``, default on), so the N-rank trajectory equals the single-process
+one on the same global batch, and the stop flag of the signal handler is agreed over
+all ranks once per step (a signal that reaches one rank stops all of them at the same
+step; rank 0 then writes the sigterm checkpoint)."""
 import signal
 
 import torch
@@ -21,6 +26,8 @@ class Trainer:
         self._max_epoch = cfg["epoch"]
         self._stop = False
         self._reducer = None
+        self._sync_bn = bool(cfg.get("sync_bn", True))
+        self._dist_ready = False
         try:
             signal.signal(signal.SIGINT, self._on_signal)
             signal.signal(signal.SIGTERM, self._on_signal)
@@ -54,9 +61,24 @@ class Trainer:
         return 0
 
     # ---- training -------------------------------------------------------------------
+    def _stop_agreed(self, model):
+        """The local flag, or -- under torch.distributed -- the OR over all ranks (and then set locally too)."""
+        if pdist.is_distributed():
+            dev = next(model.parameters()).device
+            self._stop = pdist.any_rank(self._stop, dev)
+        return self._stop
+
+    def _prepare_distributed(self, model):
+        if self._dist_ready or not pdist.is_distributed():
+            return
+        if self._sync_bn:
+            pdist.convert_sync_batchnorm(model)
+        self._reducer = pdist.GradientAllReduce(model)
+        self._dist_ready = True
+
     def train(self, model, train_loader, eval_loader=None):
         for self._epoch in range(0, self._max_epoch):
-            if self._stop:
+            if self._stop_agreed(model):
                 self._logger.save_sigterm_ckpt(model, self._optim, self._epoch, self._step)
                 return 1
             self._train_epoch(model, train_loader)
@@ -71,14 +93,13 @@ class Trainer:
         return 0
 
     def _train_batch(self, model, batch, ratio):
+        self._prepare_distributed(model)
         model.train()
         self._optim.zero_grad()
         self._optim.set_lr(self._epoch + ratio)
         loss, tb_dict, _ = model.model_fn(model, batch)
         loss.backward()
-        if pdist.is_distributed():
-            if self._reducer is None:
-                self._reducer = pdist.GradientAllReduce(model)
+        if self._reducer is not None:
             self._reducer()
         if self._grad_norm_clip > 0:
             clip_grad_norm_(model.parameters(), self._grad_norm_clip)
@@ -93,7 +114,7 @@ class Trainer:
     def _train_epoch(self, model, train_loader):
         total, n = 0.0, max(len(train_loader), 1)
         for ib, batch in enumerate(train_loader):
-            if self._stop:
+            if self._stop_agreed(model):
                 return
             total += self._train_batch(model, batch, ratio=ib / n)
             self._step += 1

@@ -33,7 +33,14 @@ class StreamingDetector:
         if not torch.cuda.is_available():
             raise RuntimeError("StreamingDetector needs the GPU (no CPU path)")
         self.model = model.to(device).eval()
-        self.model.fuse_for_inference()
+        # The captured graph bakes in the addresses of the folded trunk parameters (model._fused).  The detector
+        # therefore (i) does not re-fuse a model that is already fused -- that would free the tensors another
+        # detector's graph still replays from -- and (ii) keeps its own reference to the set it captured, so the
+        # memory outlives a later fuse_for_inference() / train() of the model; _ensure_fused() notices such a
+        # change before every step and drops the stale graph.
+        if getattr(self.model, "_fused", None) is None:
+            self.model.fuse_for_inference()
+        self._fused_ref = self.model._fused
         self.kw = dict(_DEFAULT_CUTOUT if cutout_kwargs is None else cutout_kwargs)
         self.B, self.N = int(batch), int(num_pts)
         dev = next(self.model.parameters()).device
@@ -50,6 +57,17 @@ class StreamingDetector:
 
     def reset(self):
         self._have_template = False
+
+    def _ensure_fused(self):
+        """The model was re-fused (new checkpoint) or left eval mode since the last step: fuse again if needed
+        and forget the graph captured on the old parameter tensors."""
+        if self.model.training:
+            self.model.eval()
+        if getattr(self.model, "_fused", None) is None:
+            self.model.fuse_for_inference()
+        if self.model._fused is not self._fused_ref:
+            self._fused_ref = self.model._fused
+            self._graph = None
 
     # one step on the static buffers; `first` = no template yet
     def _step(self, first):
@@ -84,6 +102,7 @@ class StreamingDetector:
 
     def __call__(self, scan):
         scan = torch.as_tensor(scan, dtype=torch.float32)
+        self._ensure_fused()
         self._scan.copy_(scan.reshape(self.B, 1, self.N), non_blocking=True)
         if not self._have_template:                   # first scan of a sequence: eager, template = its own features
             cls, reg, tmpl, fused = self._step(True)

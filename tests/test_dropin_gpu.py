@@ -711,6 +711,55 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
         tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
 
 
+def test_rccl_one_rank_smoke(tmp_path):
+    """The RCCL code path executes at least once on the one GPU of the test box: a one-rank `nccl` process group,
+    the flat gradient bucket all-reduced on device tensors, the SyncBatchNorm forward / backward collectives and the
+    agreed stop flag.  (Own process: the group must not leak into the other tests.)"""
+    import os, subprocess, sys, textwrap
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "rccl_smoke.py"
+    script.write_text(textwrap.dedent('''
+        import os, sys
+        import torch, torch.distributed as dist
+        sys.path.insert(0, os.environ["POF_REPO"])
+        sys.path.insert(0, os.path.join(os.environ["POF_REPO"], "planar_optical_flow_amd"))
+        from planar_optical_flow_amd import dist as pd
+        from src.model.get_model import get_model
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        torch.manual_seed(5)
+        ref = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda().train()
+        torch.manual_seed(5)
+        model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda()
+        pd.convert_sync_batchnorm(model).train()
+        x = torch.randn(12, 64, 3, device="cuda")
+        y = torch.randn(12, 3, device="cuda")
+        model.loss_fn(model(x), y).backward()
+        ref.loss_fn(ref(x), y).backward()
+        red = pd.GradientAllReduce(model)
+        before = [p.grad.clone() for p in red.params if p.grad is not None]
+        red(force=True)                                   # ncclAllReduce on the device bucket, one rank
+        after = [p.grad for p in red.params if p.grad is not None]
+        assert red.bucket.is_cuda and all(torch.allclose(a, b, rtol=0, atol=0) for a, b in zip(before, after))
+        # one rank: SyncBatchNorm (statistics through RCCL) == stock BatchNorm
+        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
+            if p.grad is not None:
+                assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=1e-6), n
+        t = torch.ones(4, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        assert t.sum().item() == 4.0
+        dist.destroy_process_group()
+        print("RCCL_OK")
+    '''))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", POF_REPO=repo, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
 def _bench_line(args, env_extra, timeout=400, launcher=False):
     import json, os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -906,6 +955,66 @@ def test_streaming_detector_graph_replay_equals_eager_steps():
                                                 torch.sigmoid(cls[b]).double().cpu().numpy(), reg[b].double().cpu().numpy())
             assert np.array_equal(dets[b][0], xy) and np.array_equal(dets[b][1], dc[:, 0]) and np.array_equal(inst[b], im)
     assert dn._graph is not None
+
+
+def test_streaming_detectors_share_a_model_and_survive_refusing():
+    """Two graphed detectors on ONE model: the second must not invalidate the folded trunk parameters the first
+    one's graph replays from (use-after-free); a train() / eval() round trip or a new
+    fuse_for_inference() makes a detector drop its graph and capture again.  Every step equals the eager detector."""
+    from planar_optical_flow_amd.streaming import StreamingDetector
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    torch.manual_seed(12)
+    model = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True).cuda().eval()
+    scans = torch.from_numpy(synth.make_batch(seed=23, B=1, T=12).scans).cuda()[0]         # [12, 450]
+    first = StreamingDetector(model, batch=1)
+    ref = StreamingDetector(model, batch=1, graph=False)
+    fused_before = model._fused
+    for t in range(3):                                          # eager first step, capture, one replay
+        c, r = first(scans[t])
+        ce, re_ = ref(scans[t])
+        assert torch.equal(c, ce) and torch.equal(r, re_), t
+    assert first._graph is not None
+    second = StreamingDetector(model, batch=1)                  # must reuse, not rebuild, the folded parameters
+    assert model._fused is fused_before and second._fused_ref is first._fused_ref
+    junk = [torch.randn(1 << 18, device="cuda") for _ in range(8)]   # recycle whatever the allocator has free
+    for t in range(3):
+        second(scans[t])
+    g_first = first._graph
+    for t in range(3, 6):                                       # replays of the FIRST detector after the second was built
+        c, r = first(scans[t])
+        ce, re_ = ref(scans[t])
+        assert torch.equal(c, ce) and torch.equal(r, re_), t
+    assert first._graph is g_first
+    # weights change: train-mode round trip drops the folded set; the detector notices and re-captures
+    model.train()
+    with torch.no_grad():
+        for prm in model.parameters():
+            prm.mul_(1.01)
+    model.eval()
+    for t in range(6, 9):
+        c, r = first(scans[t])
+        ce, re_ = ref(scans[t])
+        assert torch.equal(c, ce) and torch.equal(r, re_), t
+    assert first._graph is not g_first and first._fused_ref is model._fused
+    del junk
+
+
+def test_streaming_detector_single_sensor_replays():
+    """batch = 1 through five calls (eager first step, capture, three replays) against the eager detector: the
+    shape whose second replay hung in round 1 when the cutout cleared its area word with a 4-byte memset node."""
+    from planar_optical_flow_amd.streaming import StreamingDetector
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    torch.manual_seed(13)
+    model = SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True).cuda().eval()
+    scans = torch.from_numpy(synth.make_batch(seed=24, B=1, T=5).scans).cuda()[0]
+    graphed, eager = StreamingDetector(model, batch=1), StreamingDetector(model, batch=1, graph=False)
+    for t in range(5):
+        cg, rg = graphed(scans[t])
+        ce, re_ = eager(scans[t])
+        torch.cuda.synchronize()
+        assert torch.equal(cg, ce) and torch.equal(rg, re_), t
+        assert torch.equal(graphed.template, eager.template)
+    assert graphed._graph is not None
 
 
 def test_model_fn_obj_det_equals_reference(golden):

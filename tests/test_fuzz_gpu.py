@@ -153,6 +153,17 @@ def test_fuzz_nms_and_polar_grid(ops, seed):
         assert np.array_equal(inst[b].cpu().numpy(), winst)
         np.testing.assert_allclose(xy[b, :m].cpu().numpy(), wxy, rtol=0, atol=1e-12)
         assert np.array_equal(dc[b, :m].cpu().numpy(), wcls[:, 0])
+    # tied scores (a float32 sigmoid saturates to exactly 1.0 for confident points): the kernel's order is total,
+    # equal scores by descending point index
+    tied = np.round(cls * 7) / 7
+    tied[:, ::3] = 1.0
+    xy, dc, num, inst = ops.nms_predicted_center(dev(scans), tab, dev(tied), dev(reg), md)
+    for b in range(B):
+        wxy, wcls, winst = R.nms_predicted_center(scans[b], phi, tied[b][:, None], reg[b], md, stable_ties=True)
+        m = int(num[b].item())
+        assert m == len(wxy) and np.array_equal(inst[b].cpu().numpy(), winst), (seed, b)
+        np.testing.assert_allclose(xy[b, :m].cpu().numpy(), wxy, rtol=0, atol=1e-12)
+        assert np.array_equal(dc[b, :m].cpu().numpy(), wcls[:, 0])
     kw = dict(min_range=float(rng.choice([0.0, 0.5])), max_range=float(rng.choice([20.0, 29.5, 30.0])),
               range_bin_size=float(rng.choice([0.25, 0.5, 1.0])), tsdf_clip=float(rng.choice([0.0, 1.0, 2.5])),
               normalize=bool(rng.integers(0, 2)))
