@@ -388,12 +388,20 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                     a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
         }
         const double step_a = AREA ? wt.step_a[p] : 0.0;
-        // fixed-point scale of the area index: 19 fractional bits while (N + 1) * 2^19 < 2^31
-        const int area_sh = (N <= 4000) ? 19 : ((N <= 64000) ? 15 : 0);
-        const int area_mask = (1 << area_sh) - 1;
-        const double area_scale = (double)(1 << area_sh);
-        const double area_c1 = AREA ? step_a * rdphi * area_scale : 0.0;
-        const double area_c0 = AREA ? ((a0 - phi0) * rdphi + 0.5) * area_scale : 0.0;
+        // Area samples: index of sample j = rint(clip(ia(j))), ia = the same rounding sequence as idx with the
+        // finer step.  ia is a linear function of j up to ~1e-12 beams, so floor(ia + 0.5) is tracked in 32.32
+        // fixed point: q(j) = q(j0) + (j - j0) * dq, two integer adds per sample, the beam is the high word.
+        // A sample whose low word comes within 2^-22 beam of a tie (or whose window leaves the field of view)
+        // sends its output to the exact sequence instead, so the index is the reference's in every case.
+        const double area_c1 = AREA ? step_a * rdphi : 0.0;
+        const double area_c0 = AREA ? (a0 - phi0) * rdphi + 0.5 : 0.0;
+        long long area_dq = 0;
+        bool area_fast = false;
+        if (AREA) {
+            // windows that stick out of the field of view, huge N and non-finite windows take the exact loop
+            area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0;
+            area_dq = (long long)(area_c1 * 4294967296.0);
+        }
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
@@ -403,22 +411,28 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 if (AREA) {
                     // mean of s_area nearest-neighbour samples: float32 sum in order, float32 divide
                     float acc = 0.0f;
-                    {
-                        // rint(clip(ia)) as a fixed-point floor of ia + 0.5: one FMA and one
-                        // saturating conversion per area sample; lanes within 2^-(sh-1) of a tie
-                        // (or out of fixed-point range) take the exact sequence, so the index is
-                        // the reference's in every value mode
-                        const double ub = fma((double)((k0 + u) * s_area), area_c1, area_c0);
+                    bool exact = !area_fast;
+                    if (area_fast) {
+                        const double x0 = fma((double)((k0 + u) * s_area), area_c1, area_c0);   // ia(j0) + 0.5 >= 0
+                        const double fl = floor(x0);
+                        unsigned long long q = ((unsigned long long)(unsigned)(int)fl << 32) |
+                                               (unsigned long long)(unsigned)((x0 - fl) * 4294967296.0);
+                        unsigned near_tie = 0;
                         for (int s = 0; s < s_area; ++s) {
-                            const int q = (int)fma((double)s, area_c1, ub);
-                            int ri = q >> area_sh;
-                            const int fb = q & area_mask;
-                            if (fb < 2 || fb > area_mask - 2 || area_sh == 0) {
-                                double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
-                                ia = ia < 0.0 ? 0.0 : ia;
-                                ia = ia > nm1 ? nm1 : ia;
-                                ri = (int)rint(ia);
-                            }
+                            const unsigned lo32 = (unsigned)q;
+                            near_tie |= (unsigned)(lo32 + 1024u < 2048u);
+                            const float v = fetch(roff + (int)(q >> 32));
+                            acc = (s == 0) ? v : acc + v;
+                            q += (unsigned long long)area_dq;
+                        }
+                        exact = near_tie != 0;
+                    }
+                    if (exact) {
+                        for (int s = 0; s < s_area; ++s) {
+                            double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
+                            ia = ia < 0.0 ? 0.0 : ia;
+                            ia = ia > nm1 ? nm1 : ia;
+                            const int ri = (int)rint(ia);
                             const float v = fetch(roff + min(max(ri, 0), N - 1));
                             acc = (s == 0) ? v : acc + v;
                         }

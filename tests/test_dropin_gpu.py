@@ -711,53 +711,18 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
         tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
 
 
-def test_rccl_one_rank_smoke(tmp_path):
-    """The RCCL code path executes at least once on the one GPU of the test box: a one-rank `nccl` process group,
-    the flat gradient bucket all-reduced on device tensors, the SyncBatchNorm forward / backward collectives and the
-    agreed stop flag.  (Own process: the group must not leak into the other tests.)"""
-    import os, subprocess, sys, textwrap
+def test_rccl_one_rank_smoke():
+    """The RCCL code path executes at least once on the one GPU of the test box (tools/rccl_smoke.py): a one-rank
+    `nccl` process group, the flat gradient bucket all-reduced on device tensors, the SyncBatchNorm forward /
+    backward collectives.  (Own process: the group must not leak into the other tests.)"""
+    import os, subprocess, sys
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "rccl_smoke.py"
-    script.write_text(textwrap.dedent('''
-        import os, sys
-        import torch, torch.distributed as dist
-        sys.path.insert(0, os.environ["POF_REPO"])
-        sys.path.insert(0, os.path.join(os.environ["POF_REPO"], "planar_optical_flow_amd"))
-        from planar_optical_flow_amd import dist as pd
-        from src.model.get_model import get_model
-        torch.cuda.set_device(0)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
-        torch.manual_seed(5)
-        ref = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda().train()
-        torch.manual_seed(5)
-        model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda()
-        pd.convert_sync_batchnorm(model).train()
-        x = torch.randn(12, 64, 3, device="cuda")
-        y = torch.randn(12, 3, device="cuda")
-        model.loss_fn(model(x), y).backward()
-        ref.loss_fn(ref(x), y).backward()
-        red = pd.GradientAllReduce(model)
-        before = [p.grad.clone() for p in red.params if p.grad is not None]
-        red(force=True)                                   # ncclAllReduce on the device bucket, one rank
-        after = [p.grad for p in red.params if p.grad is not None]
-        assert red.bucket.is_cuda and all(torch.allclose(a, b, rtol=0, atol=0) for a, b in zip(before, after))
-        # one rank: SyncBatchNorm (statistics through RCCL) == stock BatchNorm
-        for (n, p), (_, q) in zip(model.named_parameters(), ref.named_parameters()):
-            if p.grad is not None:
-                assert torch.allclose(p.grad, q.grad, rtol=2e-4, atol=1e-6), n
-        t = torch.ones(4, device="cuda")
-        dist.all_reduce(t)
-        torch.cuda.synchronize()
-        assert t.sum().item() == 4.0
-        dist.destroy_process_group()
-        print("RCCL_OK")
-    '''))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", POF_REPO=repo, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, env=env, timeout=300)
-    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+    r = subprocess.run([sys.executable, os.path.join(repo, "tools", "rccl_smoke.py")], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stderr[-1500:]
 
 
 def _bench_line(args, env_extra, timeout=400, launcher=False):
