@@ -38,6 +38,11 @@ typedef void *pof_stream_t; /* hipStream_t */
 
 int pof_abi_version(void);
 const char *pof_error_string(int code);
+/* Every entry point starts from a clean HIP error state (so that its own launch check is meaningful).  A sticky
+ * error left by an EARLIER call of the calling thread -- the caller's own previous launch, say -- is not
+ * swallowed by that: it is parked, and this function returns it (a hipError_t value; 0 = none) and clears the
+ * slot.  Thread-local. */
+int pof_take_stale_error(void);
 
 /* ------------------------------------------------------------------------
  * A1  get_laser_phi(angle_inc, num_pts)            src/utils/utils.py:25-29

@@ -23,6 +23,7 @@ _sz = C.c_size_t
 SIGNATURES = {
     "pof_abi_version": (_i, []),
     "pof_error_string": (C.c_char_p, [_i]),
+    "pof_take_stale_error": (_i, []),
     "pof_laser_phi": (_i, [_d, _i, _p, _p]),
     "pof_scan_preprocess_workspace_bytes": (_sz, [_i, _i]),
     "pof_scan_preprocess_phase": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
@@ -118,11 +119,31 @@ def load(path=None):
     return lib
 
 
+class StaleHipError(RuntimeWarning):
+    """An earlier HIP call of this thread (not one of this library's) had failed when an entry point was
+    entered; the library took the sticky error out of the way and reports it here instead of swallowing it."""
+
+
+_STRICT = os.environ.get("POF_STRICT_ERRORS", "0") == "1"
+
+
+def take_stale_error():
+    """hipError_t code the library found pending at an entry point since the last query (0 = none)."""
+    return int(load().pof_take_stale_error())
+
+
 def call(name, *args):
     """Invoke an int-returning entry point; non-zero -> exception.
-    POF_E_BADARG maps to AssertionError like the reference's input guards."""
+    POF_E_BADARG maps to AssertionError like the reference's input guards.  With POF_STRICT_ERRORS=1 a HIP
+    error that was pending when the entry point was entered raises StaleHipError (as a warning) here."""
     lib = load()
     code = getattr(lib, name)(*args)
+    if _STRICT:
+        stale = lib.pof_take_stale_error()
+        if stale:
+            import warnings
+            warnings.warn("%s: HIP error %d was pending from an earlier call of this thread" % (name, stale),
+                          StaleHipError, stacklevel=2)
     if code != POF_OK:
         msg = lib.pof_error_string(code).decode()
         if code == POF_E_BADARG:

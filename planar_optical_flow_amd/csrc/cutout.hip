@@ -174,7 +174,7 @@ __device__ __forceinline__ float finish_value(const CutArgs &a, double ct, doubl
 //               saturated samples are exactly +-1).  Opt-in (value_mode = 1).
 //   DBG      also write the inds_ct_low debug tensor (tests only)
 template <int LDSMODE, int P4, int VMODE, bool DBG>
-__global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
+__global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = a.fixed ? a.tile * a.T : a.tile;
@@ -313,9 +313,9 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
         __syncthreads();
     }
-    auto fetch = [&](int off) -> float {
-        if (LDSMODE == 1) return s_rows[off];
-        if (LDSMODE == 2 && span_lds) return s_rows[off];
+    // row source as a compile-time tag: a pointer selected at run time would turn every tap into a flat_load
+    auto fetch_from = [&](auto lds_tag, int off) -> float {
+        if (decltype(lds_tag)::value) return s_rows[off];
         return smp[off];
     };
 
@@ -329,11 +329,10 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     _Float16 *out_tile16 = a.out16 ? a.out16 + tile_off : nullptr;
     const int tcount = a.fixed ? 1 : T;
 
-    // One (window, 4-sample group): AREA = false is the interpolation path, AREA = true the
-    // area-sampling path of windows that cover more than P raw points.  Two instantiations
-    // keep every area-only instruction (and its selects) out of the common loop.
-    auto group = [&](auto area_tag, auto full_tag, const int p, const int k0) {
-        constexpr bool AREA = decltype(area_tag)::value;
+    // One (window, KV-sample group) of the interpolation path; area-sampled windows (more than P raw points
+    // under the window) go through area_group below, so that neither path carries the other's registers.
+    auto group = [&](auto full_tag, auto lds_tag, const int p, const int k0) {
+        auto fetch = [&](int off) -> float { return fetch_from(lds_tag, off); };
         // FULL: all KV samples of this lane lie inside the field of view (phase A's k interval): no range
         // test, no index clamp, no padding select
         constexpr bool FULL = decltype(full_tag)::value;
@@ -387,65 +386,13 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
                 for (int u = 0; u < KV; ++u)
                     a.dbg_lo[(((long long)b * P + k0 + u) * T + tfirst + tt) * a.Ns + (j0 + jj)] = lo[u];
         }
-        const double step_a = AREA ? wt.step_a[p] : 0.0;
-        // Area samples: index of sample j = rint(clip(ia(j))), ia = the same rounding sequence as idx with the
-        // finer step.  ia is a linear function of j up to ~1e-12 beams, so floor(ia + 0.5) is tracked in 32.32
-        // fixed point: q(j) = q(j0) + (j - j0) * dq, two integer adds per sample, the beam is the high word.
-        // A sample whose low word comes within 2^-22 beam of a tie (or whose window leaves the field of view)
-        // sends its output to the exact sequence instead, so the index is the reference's in every case.
-        const double area_c1 = AREA ? step_a * rdphi : 0.0;
-        const double area_c0 = AREA ? (a0 - phi0) * rdphi + 0.5 : 0.0;
-        long long area_dq = 0;
-        bool area_fast = false;
-        if (AREA) {
-            // windows that stick out of the field of view, huge N and non-finite windows take the exact loop
-            area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0;
-            area_dq = (long long)(area_c1 * 4294967296.0);
-        }
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
             float res[KV];
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
                 float y;
-                if (AREA) {
-                    // mean of s_area nearest-neighbour samples: float32 sum in order, float32 divide
-                    float acc = 0.0f;
-                    bool exact = !area_fast;
-                    if (area_fast) {
-                        const double x0 = fma((double)((k0 + u) * s_area), area_c1, area_c0);   // ia(j0) + 0.5 >= 0
-                        const double fl = floor(x0);
-                        unsigned long long q = ((unsigned long long)(unsigned)(int)fl << 32) |
-                                               (unsigned long long)(unsigned)((x0 - fl) * 4294967296.0);
-                        unsigned near_tie = 0;
-                        for (int s = 0; s < s_area; ++s) {
-                            const unsigned lo32 = (unsigned)q;
-                            near_tie |= (unsigned)(lo32 + 1024u < 2048u);
-                            const float v = fetch(roff + (int)(q >> 32));
-                            acc = (s == 0) ? v : acc + v;
-                            q += (unsigned long long)area_dq;
-                        }
-                        exact = near_tie != 0;
-                    }
-                    if (exact) {
-                        for (int s = 0; s < s_area; ++s) {
-                            double ia = frac_index(a0, step_a, (double)((k0 + u) * s_area + s), phi0, dphi, rdphi);
-                            ia = ia < 0.0 ? 0.0 : ia;
-                            ia = ia > nm1 ? nm1 : ia;
-                            const int ri = (int)rint(ia);
-                            const float v = fetch(roff + min(max(ri, 0), N - 1));
-                            acc = (s == 0) ? v : acc + v;
-                        }
-                    }
-                    const float mean_a = __fdiv_rn(acc, (float)s_area);
-                    if (VMODE == 2) {
-                        const float df = (float)dd;
-                        y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
-                                       : mean_a;
-                    } else {
-                        y = finish_value<VMODE>(a, (double)mean_a, dd);
-                    }
-                } else {
+                {
                     float vlo, vhi;
                     if (LDSMODE == 1) {
                         // both taps with one LDS access (adjacent words).  At lo = N-1 the second tap is the
@@ -505,6 +452,94 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         }
     };
 
+    // Area-sampled windows: output k = float32 mean, in sample order, of the s_area nearest-neighbour samples
+    // j = k * s_area ... of the finer grid.  Index of sample j = rint(clip(ia(j))), ia = the rounding sequence
+    // of idx with the finer step.  ia is a linear function of j up to ~1e-12 beams, so floor(ia + 0.5) is
+    // tracked in 32.32 fixed point: q(j + 1) = q(j) + dq, two integer adds per sample, the beam is the high
+    // word, four loads in flight.  An output with a sample whose low word comes within 2^-22 beam of a tie
+    // (and every window that leaves the field of view) is summed again with the exact sequence, so the
+    // indices are the reference's in every case.  One output at a time per lane (scalar stores): the sums are
+    // serial anyway, and unrolling them across outputs only costs registers.
+    auto area_group = [&](auto lds_tag, const int p, const int k0) {
+        auto fetch = [&](int off) -> float { return fetch_from(lds_tag, off); };
+        const double a0 = wt.a0[p], step = wt.step[p], step_a = wt.step_a[p];
+        const double dd = wt.dd[p];
+        const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
+        const int out_off = wt.out_off[p], row_off = wt.row_off[p];
+        const int kr = wt.krange[p];
+        const int klo = kr & 0xffff, khi = kr >> 16;
+        const double area_c1 = step_a * rdphi;
+        const double area_c0 = (a0 - phi0) * rdphi + 0.5;
+        // windows that stick out of the field of view, huge N and non-finite windows take the exact loop
+        const bool area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0;
+        const unsigned long long dq = area_fast ? (unsigned long long)(area_c1 * 4294967296.0) : 0ull;
+        for (int tt = 0; tt < tcount; ++tt) {
+            const int roff = (row_off + tt) * rstride + rbase;
+            const int o_el = out_off + tt * P + k0;
+#pragma unroll 1
+            for (int u = 0; u < KV; ++u) {
+                const int k = k0 + u;
+                float acc = 0.0f;
+                bool exact = !area_fast;
+                if (area_fast) {
+                    const double x0 = fma((double)(k * s_area), area_c1, area_c0);   // ia(j0) + 0.5 >= 0
+                    const double fl = floor(x0);
+                    unsigned long long q = ((unsigned long long)(unsigned)(int)fl << 32) |
+                                           (unsigned long long)(unsigned)((x0 - fl) * 4294967296.0);
+                    bool near_tie = false;
+                    int sdone = 0;
+                    for (; sdone + 4 <= s_area; sdone += 4) {
+                        const unsigned long long q1 = q + dq, q2 = q1 + dq, q3 = q2 + dq;
+                        const float v0 = fetch(roff + (int)(q >> 32)), v1 = fetch(roff + (int)(q1 >> 32));
+                        const float v2 = fetch(roff + (int)(q2 >> 32)), v3 = fetch(roff + (int)(q3 >> 32));
+                        near_tie |= ((unsigned)q + 1024u < 2048u) | ((unsigned)q1 + 1024u < 2048u) |
+                                    ((unsigned)q2 + 1024u < 2048u) | ((unsigned)q3 + 1024u < 2048u);
+                        acc = (sdone == 0) ? v0 : acc + v0;
+                        acc = acc + v1;
+                        acc = acc + v2;
+                        acc = acc + v3;
+                        q = q3 + dq;
+                    }
+                    for (; sdone < s_area; ++sdone) {
+                        near_tie |= (unsigned)q + 1024u < 2048u;
+                        const float v = fetch(roff + (int)(q >> 32));
+                        acc = (sdone == 0) ? v : acc + v;
+                        q += dq;
+                    }
+                    exact = near_tie;
+                }
+                if (exact) {
+                    for (int s = 0; s < s_area; ++s) {
+                        double ia = frac_index(a0, step_a, (double)(k * s_area + s), phi0, dphi, rdphi);
+                        ia = ia < 0.0 ? 0.0 : ia;
+                        ia = ia > nm1 ? nm1 : ia;
+                        const int ri = (int)rint(ia);
+                        const float v = fetch(roff + min(max(ri, 0), N - 1));
+                        acc = (s == 0) ? v : acc + v;
+                    }
+                }
+                const float mean_a = __fdiv_rn(acc, (float)s_area);
+                float y;
+                if (VMODE == 2) {
+                    const float df = (float)dd;
+                    y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
+                                   : mean_a;
+                } else {
+                    y = finish_value<VMODE>(a, (double)mean_a, dd);
+                }
+                y = __builtin_amdgcn_fmed3f(y, ylo, yhi);
+                if (k < klo || k > khi) y = ypad;
+                if (DBG) {
+                    const double idx = frac_index(a0, step, (double)k, phi0, dphi, rdphi);
+                    const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
+                    a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = min(max((int)idx, 0), N - 1);
+                }
+                if (out_tile16) out_tile16[o_el + u] = (_Float16)y;
+                else out_tile[o_el + u] = y;
+            }
+        }
+    };
+
     // B1: every window that is not area-sampled.  The lanes of a wave whose samples all lie inside the field of
     // view (all but the windows at the two ends of the scan) take the variant without range tests.
     for (int g0 = 0; g0 < total; g0 += kThreads) {
@@ -515,8 +550,12 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
         const bool work = act && !wt.isarea[p];
         const int kr = wt.krange[p];
         const bool full = (kr & 0xffff) <= k0 && k0 + KV - 1 <= (kr >> 16);
-        if (__all(full || !work)) {
-            if (work) group(std::false_type{}, std::true_type{}, p, k0);
+        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds)) {
+            if (__all(full || !work)) {
+                if (work) group(std::true_type{}, std::true_type{}, p, k0);
+            } else {
+                if (work) group(std::false_type{}, std::true_type{}, p, k0);
+            }
         } else {
             if (work) group(std::false_type{}, std::false_type{}, p, k0);
         }
@@ -525,7 +564,10 @@ __global__ __launch_bounds__(kThreads) void cutout_kernel(CutArgs a)
     const int n_area = s_area > 0 ? s_acount : 0;
     for (int g = threadIdx.x; g < n_area * per_win; g += kThreads) {
         const int q = (P4 > 0) ? g / P4 : g / per_win;
-        group(std::true_type{}, std::false_type{}, wt.alist[q], (g - q * per_win) * KV);
+        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds))
+            area_group(std::true_type{}, wt.alist[q], (g - q * per_win) * KV);
+        else
+            area_group(std::false_type{}, wt.alist[q], (g - q * per_win) * KV);
     }
 }
 

@@ -7,10 +7,16 @@
 
 #define POF_WAVE 64
 
-// hipGetLastError() reports (and clears) the last error of ANY earlier HIP call of this
-// thread -- e.g. a benign one inside the caller's framework.  Every entry point therefore
-// drops stale state first, so that POF_CHECK_LAUNCH() only sees its own launches.
-#define POF_CLEAR_STALE_ERROR() (void)hipGetLastError()
+// hipGetLastError() reports (and clears) the last error of ANY earlier HIP call of this thread -- e.g. one
+// raised by the caller's own previous launch.  Every entry point takes that state first, so that
+// POF_CHECK_LAUNCH() only sees its own launches -- but it does not swallow it: the code is parked in a
+// thread-local slot that the caller reads (and clears) with pof_take_stale_error().
+extern thread_local int pof_stale_error_slot;
+#define POF_CLEAR_STALE_ERROR()                                  \
+    do {                                                         \
+        const hipError_t stale_ = hipGetLastError();             \
+        if (stale_ != hipSuccess) pof_stale_error_slot = (int)stale_; \
+    } while (0)
 
 #define POF_CHECK_LAUNCH()                                   \
     do {                                                     \

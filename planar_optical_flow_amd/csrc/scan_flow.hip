@@ -1339,6 +1339,15 @@ extern "C" int pof_canonical_to_det(const float *ranges, const double *tab, cons
 
 extern "C" int pof_abi_version(void) { return POF_ABI_VERSION; }
 
+thread_local int pof_stale_error_slot = 0;
+
+extern "C" int pof_take_stale_error(void)
+{
+    const int e = pof_stale_error_slot;
+    pof_stale_error_slot = 0;
+    return e;
+}
+
 extern "C" const char *pof_error_string(int code)
 {
     switch (code) {

@@ -56,7 +56,8 @@ def test_every_entry_point_rejects_null_arguments(lib):
     negative status (no launch, no fault); the wrapper maps POF_E_BADARG to AssertionError."""
     import ctypes as C
     from planar_optical_flow_amd import _lib
-    skip = {"pof_abi_version", "pof_error_string", "pof_scan_preprocess_workspace_bytes", "pof_nms_workspace_bytes"}
+    skip = {"pof_abi_version", "pof_error_string", "pof_scan_preprocess_workspace_bytes", "pof_nms_workspace_bytes",
+            "pof_take_stale_error"}
     for name, (restype, argtypes) in _lib.SIGNATURES.items():
         if name in skip or restype is not C.c_int:
             continue

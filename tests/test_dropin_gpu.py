@@ -711,6 +711,35 @@ def test_train_utils_trainer_on_device_loader(golden, tmp_path):
         tu.load_checkpoint(model, None, filename=str(tmp_path / "missing.pth"))
 
 
+def test_stale_hip_error_is_surfaced_not_swallowed():
+    """A sticky HIP error left by an earlier call of the thread (here: hipSetDevice on a device that does not
+    exist) is taken out of the way by the next entry point -- whose own launch check must not trip over it --
+    and handed to the caller through pof_take_stale_error() (the blanket clear hid it)."""
+    import ctypes as C
+    from planar_optical_flow_amd import _lib, ops
+    lib = _lib.load()
+    lib.pof_take_stale_error()                                   # start clean
+    tab = ops.phi_table()
+    torch.cuda.synchronize()
+    # the HIP runtime this process already runs on (torch's copy): found in the process map, not by soname
+    paths = {ln.split()[-1] for ln in open("/proc/self/maps") if "libamdhip64" in ln}
+    assert len(paths) == 1, paths
+    hip = C.CDLL(paths.pop())
+    dev = torch.cuda.current_device()
+    scans = torch.rand(2, 1, 450, device="cuda") * 10 + 1
+    out = ops.scan_preprocess(scans, tab, want=("xy",))          # warm-up: buffers come from torch's cache below
+    ws = torch.empty(ops.scan_preprocess_workspace_bytes(2, 0), dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    rc = hip.hipSetDevice(9999)
+    assert rc != 0                                               # hipErrorInvalidDevice, now sticky
+    hip.hipSetDevice(dev)
+    ops.scan_preprocess(scans, tab, want=("xy",), out=out, workspace=ws)   # succeeds: its launch check saw a clean state
+    assert _lib.take_stale_error() == rc                         # ... and the earlier error is reported
+    assert _lib.take_stale_error() == 0                          # once
+    torch.cuda.synchronize()
+    assert torch.isfinite(out["xy"]).all()
+
+
 def test_rccl_one_rank_smoke():
     """The RCCL code path executes at least once on the one GPU of the test box (tools/rccl_smoke.py): a one-rank
     `nccl` process group, the flat gradient bucket all-reduced on device tensors, the SyncBatchNorm forward /
