@@ -72,8 +72,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--ring", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--pipeline", action="store_true",
-                    help="graph: params launch of batch i+1 on a second stream (measured: no gain, see DESIGN.md)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="independent batches in flight: batch i is launched on stream i %% S and evaluates the params "
+                         "of batch i + S (2: the dependent-launch boundary and the ramp / tail of one batch's launch "
+                         "are covered by the next batch's; 1: one launch at a time)")
     ap.add_argument("--no-chain", dest="chained", action="store_false",
                     help="two launches per step (params + streaming) instead of the chained single launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -233,7 +235,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(sbm):
+    def measure(sbm, n_streams):
         """Ring of resident batches + hipGraph of one trip round it; W warm-up steps, then `repeats` timed regions
         of EXACTLY K steps, each bracketed by barrier + synchronize, wall time maximised over ranks.
         -> dict(wall_s [repeats], dev_ms [repeats], ring)"""
@@ -259,19 +261,40 @@ def main():
             ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, len(rr)), dtype=torch.uint8, device=dev)
             ring.append((scans, o0, o1, det, outs, ws))
 
+        S = max(1, min(n_streams, a.ring)) if a.chained else 1
+        assert a.ring % S == 0, "--ring must be a multiple of --streams"
+
         def step(i, phases=3):
             scans, o0, o1, det, outs, ws = ring[i % a.ring]
             if a.chained and phases == 3:
-                # one launch: stream batch i (its params were produced by the previous step's launch)
-                # and evaluate the params of batch i+1 on extra workgroups of the same grid
-                _, n0, n1, ndet, _, nws = ring[(i + 1) % a.ring]
+                # one launch: stream batch i (its params were produced by launch i - S) and evaluate the params
+                # of batch i + S on extra workgroups of the same grid
+                _, n0, n1, ndet, _, nws = ring[(i + S) % a.ring]
                 ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws,
                                     next_batch={"odom0": n0, "odom1": n1, "dets": ndet, "workspace": nws})
             else:
                 ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
 
         if a.chained:
-            step(0, phases=1)  # prime the chain: params of ring slot 0
+            for k in range(S):
+                step(k, phases=1)  # prime the chains: params of the first S ring slots
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+
+        def trip(n):
+            """n consecutive steps; with S > 1 step i goes to stream i % S (independent batches, each stream's
+            chain is ordered by the stream), forked from and joined to the current stream."""
+            if S == 1:
+                for i in range(n):
+                    step(i)
+                return
+            cur = torch.cuda.current_stream()
+            for ln in lanes:
+                ln.wait_stream(cur)
+            for i in range(n):
+                with torch.cuda.stream(lanes[i % S]):
+                    step(i)
+            for ln in lanes:
+                cur.wait_stream(ln)
 
         # ---- optional hipGraph of one trip round the ring --------------------------
         graph = None
@@ -279,44 +302,22 @@ def main():
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for i in range(a.ring):
-                    step(i)
+                trip(a.ring)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
-                if not a.pipeline:
-                    for i in range(a.ring):
-                        step(i)
-                else:
-                    # two-stream software pipeline over the independent batches of the ring: the
-                    # tiny per-sample params launch of batch i+1 runs under the streaming launch of
-                    # batch i (each batch has its own workspace; an event orders params(i) -> main(i))
-                    main_s = torch.cuda.current_stream()
-                    side2 = torch.cuda.Stream()
-                    side2.wait_stream(main_s)
-                    evs = []
-                    with torch.cuda.stream(side2):
-                        for i in range(a.ring):
-                            step(i, phases=1)
-                            ev = torch.cuda.Event()
-                            ev.record(side2)
-                            evs.append(ev)
-                    for i in range(a.ring):
-                        main_s.wait_event(evs[i])
-                        step(i, phases=2)
-                    main_s.wait_stream(side2)
+                trip(a.ring)
 
         # K or W need not be multiples of the ring: the remainder steps get their own captured graph
         # (an eager launch costs tens of microseconds of Python per step, several times the kernel)
         rem_graphs = {}
-        if graph is not None and not a.pipeline:
+        if graph is not None:
             for rem in sorted({a.steps % a.ring, a.warmup % a.ring} - {0}):
                 torch.cuda.synchronize()
                 gr = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gr):
-                    for i in range(rem):
-                        step(i)
+                    trip(rem)
                 rem_graphs[rem] = gr
 
         def run(k):
@@ -327,11 +328,12 @@ def main():
                 if rem in rem_graphs:
                     rem_graphs[rem].replay()
                 else:
-                    for i in range(rem):
-                        step(i)
+                    trip(rem)
             else:
-                for i in range(k):
-                    step(i)
+                full, rem = divmod(k, a.ring)
+                for _ in range(full):
+                    trip(a.ring)
+                trip(rem)
 
         run(a.warmup)
         walls, devs = [], []
@@ -350,9 +352,11 @@ def main():
                 dt = float(t.item())
             walls.append(dt)
             devs.append(ev0.elapsed_time(ev1))
-        return {"wall_s": walls, "dev_ms": devs, "ring": ring, "graph": graph is not None}
+        return {"wall_s": walls, "dev_ms": devs, "ring": ring, "graph": graph is not None, "streams": S}
 
-    weak = measure(sb)
+    weak = measure(sb, a.streams)
+    # the same steps one launch at a time (the per-kernel duration rocprofv3 reports is comparable with THIS)
+    single = measure(sb, 1) if (a.streams > 1 and a.chained) else None
     dt = float(np.median(weak["wall_s"]))
     dev_ms = float(np.median(weak["dev_ms"]))
     ring = weak["ring"]
@@ -366,7 +370,7 @@ def main():
         import copy
         sbs = copy.copy(sbg)
         sbs.scans, sbs.odom0, sbs.odom1, sbs.dets = sbg.scans[sl], sbg.odom0[sl], sbg.odom1[sl], sbg.dets[sl]
-        st = measure(sbs)
+        st = measure(sbs, a.streams)
         sdt = float(np.median(st["wall_s"]))
         strong = {"value": B * a.steps / sdt, "unit": "scans/s", "ms_per_step": sdt / a.steps * 1e3,
                   "scans_per_rank_per_step": per, "global_batch": B,
@@ -419,9 +423,12 @@ def main():
                                    "(A1-A7 fused: xy, displacement flow, canonical frame, association, "
                                    "regression target, exclude mask), float32 outputs" % B,
                        "global_batch": world * B, "ring_batches": a.ring,
-                       "launch": ("eager" if not graph else
-                                  "hipGraph replay" + (", params launch of batch i+1 on a second stream" if a.pipeline else "")
-                                  + (", chained (params of batch i+1 ride in the launch of batch i)" if a.chained else "")),
+                       "launch": ("eager" if not graph else "hipGraph replay")
+                                 + (", chained (the params of batch i+%d ride in the launch of batch i)" % weak["streams"]
+                                    if a.chained else "")
+                                 + (", %d independent batches in flight on %d HIP streams" % (weak["streams"], weak["streams"])
+                                    if weak["streams"] > 1 else ""),
+                       "streams": weak["streams"],
                        "parallelism": "weak: batch-sharded x%d, %d scans per rank and step, no data-path collective" % (world, B),
                        "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
                        "collective_backend": (backend if world > 1 else None)},
@@ -431,8 +438,21 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
                          "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms,
-                         "launch_ms_min": min(weak["dev_ms"]) / a.steps, "launch_ms_max": max(weak["dev_ms"]) / a.steps},
+                         "launch_ms_min": min(weak["dev_ms"]) / a.steps, "launch_ms_max": max(weak["dev_ms"]) / a.steps,
+                         "concurrent_launches": weak["streams"],
+                         "note": ("launch_ms = device time of the timed region / launches" +
+                                  ("; %d launches (independent batches) are in flight at a time, so a per-kernel "
+                                   "duration as rocprofv3 lists it is about %d x launch_ms -- compare it with "
+                                   "single_stream.launch_ms" % (weak["streams"], weak["streams"])
+                                   if weak["streams"] > 1 else ""))},
         }
+        if single is not None:
+            s_dev = float(np.median(single["dev_ms"])) / a.steps
+            s_wall = float(np.median(single["wall_s"]))
+            s_ach = bytes_per_scan * B / (s_dev * 1e-3) / 1e9
+            result["single_stream"] = {"value": world * B * a.steps / s_wall, "ms_per_step": s_wall / a.steps * 1e3,
+                                       "launch_ms": s_dev, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
+                                       "note": "the same K steps, one launch at a time on one stream"}
         if strong is not None:
             result["strong_scaling"] = strong
         if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line

@@ -13,7 +13,7 @@ transposed form), so SpatialDROW trains through the gate.
 import torch
 import torch.nn as nn
 
-from planar_optical_flow_amd import ops
+from planar_optical_flow_amd import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.pof.*)
 
 
 def flow_loss(pred, target, mask=None):
@@ -21,24 +21,17 @@ def flow_loss(pred, target, mask=None):
     return torch.mean(err[mask == 1.0]) if mask is not None else torch.mean(err)
 
 
-class _WindowedAttention(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, emb_x, emb_t, x, tmpl, alpha, window):
-        ex, et = emb_x.contiguous().float(), emb_t.contiguous().float()
-        xx, tt = x.contiguous().float(), tmpl.contiguous().float()
-        out, band, prob = ops.spatial_attention(ex, et, xx, tt, alpha, window)
-        ctx.save_for_backward(ex, et, tt, prob)
-        ctx.cfg = (alpha, window)
-        return out, band
+class _WindowedAttention:
+    """The gate's banded similarity / softmax / template merge as the registered operator
+    ``torch.ops.pof.spatial_attention`` (planar_optical_flow_amd/torch_ops.py: HIP forward and backward kernels,
+    autograd formula and fake kernel registered with torch.library, so autograd and torch.compile see one op)."""
 
     @staticmethod
-    def backward(ctx, g_out, g_band):
-        ex, et, tt, prob = ctx.saved_tensors
-        alpha, window = ctx.cfg
-        gb = None if g_band is None else g_band.contiguous().float()
-        dex, det, dx, dt = ops.spatial_attention_backward(ex, et, tt, prob, g_out.contiguous().float(), gb,
-                                                          alpha, window)
-        return dex, det, dx.view_as(g_out), dt.view_as(g_out), None, None
+    def apply(emb_x, emb_t, x, tmpl, alpha, window):
+        out, band, _ = torch.ops.pof.spatial_attention(emb_x.contiguous().float(), emb_t.contiguous().float(),
+                                                       x.contiguous().float(), tmpl.contiguous().float(),
+                                                       float(alpha), int(window))
+        return out, band
 
 
 class _SpatialAttention(nn.Module):

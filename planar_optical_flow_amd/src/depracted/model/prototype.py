@@ -8,29 +8,16 @@ with the torch encoder/decoder for end-to-end training.
 """
 import torch
 
-from planar_optical_flow_amd import ops
-
-
-class _BandCorrelation(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, feat1, feat2, kernel_size, max_displacement):
-        f1, f2 = feat1.contiguous().float(), feat2.contiguous().float()
-        ctx.save_for_backward(f1, f2)
-        ctx.cfg = (kernel_size, max_displacement)
-        return ops.band_correlation(f1, f2, kernel_size, max_displacement)
-
-    @staticmethod
-    def backward(ctx, grad):
-        f1, f2 = ctx.saved_tensors
-        d1, d2 = ops.band_correlation_backward(f1, f2, grad.contiguous().float(), *ctx.cfg)
-        return d1, d2, None, None
+from planar_optical_flow_amd import ops, torch_ops  # noqa: F401  (torch_ops registers torch.ops.pof.*)
 
 
 def fusion(feat1, feat2, kernel_size=3, max_displacement=5):
     """(B,C,n) x2 -> (B, 2*max_displacement+1, n): correlation of the clamped
     `kernel_size`-tap patch around i in feat1 with the patches around
-    clamp(i+d) in feat2, d in [-max_displacement, +max_displacement]."""
-    return _BandCorrelation.apply(feat1, feat2, kernel_size, max_displacement)
+    clamp(i+d) in feat2, d in [-max_displacement, +max_displacement].  The registered operator
+    ``torch.ops.pof.band_correlation`` (torch_ops.py): HIP forward / backward, autograd formula, fake kernel."""
+    return torch.ops.pof.band_correlation(feat1.contiguous().float(), feat2.contiguous().float(), int(kernel_size),
+                                          int(max_displacement))
 
 
 def flow_loss(pred, target, mask=None):

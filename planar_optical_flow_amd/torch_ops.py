@@ -1,0 +1,171 @@
+"""torch.library registration of the HIP ops: ``torch.ops.pof.*``.
+
+The C-ABI entry points are reached through ``ops.py`` (ctypes); registering them as custom operators makes them
+first-class for the dispatcher: autograd formulas instead of hand-rolled ``autograd.Function`` objects, fake
+(meta) kernels so that ``torch.compile`` / ``make_fx`` / FakeTensorMode can trace through a model that calls them
+without running a kernel, and an ``opcheck``-able schema.  Device kernels only: a CPU tensor raises (no fallback).
+
+    pof::band_correlation(Tensor f1, Tensor f2, int kernel_size, int max_displacement) -> Tensor
+    pof::band_correlation_backward(Tensor f1, Tensor f2, Tensor g, int kernel_size, int max_displacement)
+        -> (Tensor, Tensor)
+    pof::spatial_attention(Tensor emb_x, Tensor emb_t, Tensor x, Tensor tmpl, float alpha, int window)
+        -> (Tensor out, Tensor band, Tensor prob)
+    pof::spatial_attention_backward(Tensor emb_x, Tensor emb_t, Tensor tmpl, Tensor prob, Tensor g_out,
+        Tensor? g_band, float alpha, int window) -> (Tensor, Tensor, Tensor, Tensor)
+    pof::cutout(Tensor scans, Tensor tab, int stride, bool centered, bool fixed, float window_width,
+        float window_depth, int num_cutout_pts, float padding_val, bool area_mode, bool half_out) -> Tensor
+    pof::conv3_bn_lrelu(Tensor x, Tensor wt, Tensor scale, Tensor shift, bool pool, float negative_slope) -> Tensor
+    pof::rotate_flow(Tensor flow, Tensor tab, bool to_canonical) -> Tensor
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+
+# ------------------------------------------------------------------------------------------------- A9
+@torch.library.custom_op("pof::band_correlation", mutates_args=(), device_types="cuda")
+def band_correlation(f1: torch.Tensor, f2: torch.Tensor, kernel_size: int, max_displacement: int) -> torch.Tensor:
+    return ops.band_correlation(f1.contiguous(), f2.contiguous(), kernel_size, max_displacement)
+
+
+@band_correlation.register_fake
+def _(f1, f2, kernel_size, max_displacement):
+    B, _, n = f1.shape
+    return f1.new_empty((B, 2 * max_displacement + 1, n), dtype=torch.float32)
+
+
+@torch.library.custom_op("pof::band_correlation_backward", mutates_args=(), device_types="cuda")
+def band_correlation_backward(f1: torch.Tensor, f2: torch.Tensor, g: torch.Tensor, kernel_size: int,
+                              max_displacement: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    d1, d2 = ops.band_correlation_backward(f1.contiguous(), f2.contiguous(), g.contiguous().float(), kernel_size,
+                                           max_displacement)
+    return d1, d2
+
+
+@band_correlation_backward.register_fake
+def _(f1, f2, g, kernel_size, max_displacement):
+    return torch.empty_like(f1, dtype=torch.float32), torch.empty_like(f2, dtype=torch.float32)
+
+
+def _corr_setup(ctx, inputs, output):
+    f1, f2, ctx.kernel_size, ctx.max_displacement = inputs
+    ctx.save_for_backward(f1, f2)
+
+
+def _corr_backward(ctx, grad):
+    f1, f2 = ctx.saved_tensors
+    d1, d2 = torch.ops.pof.band_correlation_backward(f1, f2, grad, ctx.kernel_size, ctx.max_displacement)
+    return d1, d2, None, None
+
+
+band_correlation.register_autograd(_corr_backward, setup_context=_corr_setup)
+
+
+# ------------------------------------------------------------------------------------------------- A10
+@torch.library.custom_op("pof::spatial_attention", mutates_args=(), device_types="cuda")
+def spatial_attention(emb_x: torch.Tensor, emb_t: torch.Tensor, x: torch.Tensor, tmpl: torch.Tensor, alpha: float,
+                      window: int) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    out, band, prob = ops.spatial_attention(emb_x.contiguous(), emb_t.contiguous(), x.contiguous(), tmpl.contiguous(),
+                                            alpha, window)
+    return out, band, prob
+
+
+@spatial_attention.register_fake
+def _(emb_x, emb_t, x, tmpl, alpha, window):
+    B, N, _ = emb_x.shape
+    w = 2 * int(window / 2) + 1
+    return (torch.empty_like(x), emb_x.new_empty((B, N, w), dtype=torch.float32),
+            emb_x.new_empty((B, N, w), dtype=torch.float32))
+
+
+@torch.library.custom_op("pof::spatial_attention_backward", mutates_args=(), device_types="cuda")
+def spatial_attention_backward(emb_x: torch.Tensor, emb_t: torch.Tensor, tmpl: torch.Tensor, prob: torch.Tensor,
+                               g_out: torch.Tensor, g_band: Optional[torch.Tensor], alpha: float, window: int
+                               ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    gb = None if g_band is None else g_band.contiguous().float()
+    dex, det, dx, dt = ops.spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out.contiguous().float(), gb, alpha,
+                                                      window)
+    return dex, det, dx, dt
+
+
+@spatial_attention_backward.register_fake
+def _(emb_x, emb_t, tmpl, prob, g_out, g_band, alpha, window):
+    return (torch.empty_like(emb_x), torch.empty_like(emb_t), torch.empty_like(tmpl, dtype=torch.float32),
+            torch.empty_like(tmpl, dtype=torch.float32))
+
+
+def _attn_setup(ctx, inputs, output):
+    emb_x, emb_t, _, tmpl, ctx.alpha, ctx.window = inputs
+    ctx.save_for_backward(emb_x, emb_t, tmpl, output[2])
+    ctx.set_materialize_grads(False)
+
+
+def _attn_backward(ctx, g_out, g_band, g_prob):
+    emb_x, emb_t, tmpl, prob = ctx.saved_tensors
+    if g_prob is not None:
+        raise RuntimeError("pof::spatial_attention: the softmax weights are an auxiliary output without a gradient")
+    if g_out is None:
+        g_out = torch.zeros_like(tmpl, dtype=torch.float32)
+    dex, det, dx, dt = torch.ops.pof.spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out, g_band, ctx.alpha,
+                                                                ctx.window)
+    return dex, det, dx, dt, None, None
+
+
+spatial_attention.register_autograd(_attn_backward, setup_context=_attn_setup)
+
+
+# ------------------------------------------------------------------------------------------------- A8
+@torch.library.custom_op("pof::cutout", mutates_args=(), device_types="cuda")
+def cutout(scans: torch.Tensor, tab: torch.Tensor, stride: int, centered: bool, fixed: bool, window_width: float,
+           window_depth: float, num_cutout_pts: int, padding_val: float, area_mode: bool, half_out: bool
+           ) -> torch.Tensor:
+    return ops.cutout(scans.contiguous(), tab, stride=stride, centered=centered, fixed=fixed,
+                      window_width=window_width, window_depth=window_depth, num_cutout_pts=num_cutout_pts,
+                      padding_val=padding_val, area_mode=area_mode,
+                      out_dtype=torch.float16 if half_out else torch.float32)
+
+
+@cutout.register_fake
+def _(scans, tab, stride, centered, fixed, window_width, window_depth, num_cutout_pts, padding_val, area_mode, half_out):
+    B, T, N = scans.shape
+    return scans.new_empty((B, (N + stride - 1) // stride, T, num_cutout_pts),
+                           dtype=torch.float16 if half_out else torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------- N2
+@torch.library.custom_op("pof::conv3_bn_lrelu", mutates_args=(), device_types="cuda")
+def conv3_bn_lrelu(x: torch.Tensor, wt: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, pool: bool,
+                   negative_slope: float) -> torch.Tensor:
+    return ops.conv3_bn_lrelu(x.contiguous(), wt, scale, shift, pool=pool, negative_slope=negative_slope)
+
+
+@conv3_bn_lrelu.register_fake
+def _(x, wt, scale, shift, pool, negative_slope):
+    S, _, L = x.shape
+    return x.new_empty((S, wt.shape[2], L // 2 if pool else L))
+
+
+# ------------------------------------------------------------------------------------------------- A4
+@torch.library.custom_op("pof::rotate_flow", mutates_args=(), device_types="cuda")
+def rotate_flow(flow: torch.Tensor, tab: torch.Tensor, to_canonical: bool) -> torch.Tensor:
+    return ops.rotate_flow(flow.contiguous(), tab, to_canonical)
+
+
+@rotate_flow.register_fake
+def _(flow, tab, to_canonical):
+    return torch.empty_like(flow)
+
+
+def _rot_setup(ctx, inputs, output):
+    _, tab, ctx.to_canonical = inputs
+    ctx.save_for_backward(tab)
+
+
+def _rot_backward(ctx, g):
+    (tab,) = ctx.saved_tensors
+    # the per-point rotation is orthogonal: the gradient is the inverse rotation of the incoming gradient
+    return torch.ops.pof.rotate_flow(g, tab, not ctx.to_canonical), None, None
+
+
+rotate_flow.register_autograd(_rot_backward, setup_context=_rot_setup)

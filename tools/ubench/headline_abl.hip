@@ -21,6 +21,11 @@ struct Slot {
 int main(int argc, char **argv)
 {
     const int B = argc > 1 ? atoi(argv[1]) : 4096, N = 450, RING = 8, ITERS = 400;
+    // argv[2] = number of streams: batch i runs on stream i % NS and evaluates the params of batch i + NS, so
+    // that consecutive launches (independent batches) may overlap their ramp and tail
+    const int NS = argc > 2 ? atoi(argv[2]) : 1;
+    hipStream_t streams[4];
+    for (int i = 0; i < NS; ++i) CK(hipStreamCreate(&streams[i]));
     double *tab; CK(hipMalloc(&tab, 3 * N * sizeof(double)));
     if (pof_laser_phi(0.5 * M_PI / 180.0, N, tab, nullptr)) return 1;
     std::mt19937 rng(7);
@@ -57,7 +62,8 @@ int main(int argc, char **argv)
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         auto run = [&](const char *name, bool flow, bool assoc, bool mask, double bytes_per_pt) {
             auto step = [&](int i) {
-                Slot &s = ring[i % RING], &n = ring[(i + 1) % RING];
+                Slot &s = ring[i % RING], &n = ring[(i + NS) % RING];
+                hipStream_t st = NS > 1 ? streams[i % NS] : nullptr;
                 const bool dets = ndet >= 0 && (assoc || mask);
                 pof_scan_inputs nx = {};
                 nx.odom0 = n.o0; nx.odom1 = n.o1; nx.B = B; nx.want_flow = flow;
@@ -67,12 +73,12 @@ int main(int argc, char **argv)
                 int rc = pof_scan_preprocess_chained(s.scans + N, 2 * N, B, N, tab, s.o0, s.o1, 0, 1, 0, nullptr,
                                                      flow ? s.flow : nullptr, dets ? s.offs : nullptr, s.rphi, s.cls, s.D, ar, lb, dr,
                                                      nullptr, (dets && assoc) ? s.tcls : nullptr, (dets && assoc) ? s.reg : nullptr, nullptr, nullptr,
-                                                     mask ? s.mask : nullptr, s.ws, s.ws_bytes, &nx, nullptr);
+                                                     mask ? s.mask : nullptr, s.ws, s.ws_bytes, &nx, st);
                 if (rc) { printf("rc %d\n", rc); exit(1); }
             };
-            // prime: params of slot 0
-            {
-                Slot &s = ring[0];
+            // prime: params of the first NS slots
+            for (int k = 0; k < NS; ++k) {
+                Slot &s = ring[k];
                 pof_scan_preprocess_phase(s.scans + N, 2 * N, B, N, tab, s.o0, s.o1, 0, 1, 0, nullptr, s.flow,
                                           ndet >= 0 ? s.offs : nullptr, s.rphi, s.cls, s.D, ar, lb, dr, nullptr, nullptr, nullptr,
                                           nullptr, nullptr, nullptr, s.ws, s.ws_bytes, 1, nullptr);
