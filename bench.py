@@ -72,9 +72,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--ring", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=4,
                     help="independent batches in flight: batch i is launched on stream i %% S and evaluates the params "
-                         "of batch i + S (2: the dependent-launch boundary and the ramp / tail of one batch's launch "
+                         "of batch i + S (the dependent-launch boundary and the ramp / tail of one batch's launch "
                          "are covered by the next batch's; 1: one launch at a time)")
     ap.add_argument("--no-chain", dest="chained", action="store_false",
                     help="two launches per step (params + streaming) instead of the chained single launch")
@@ -296,39 +296,46 @@ def main():
             for ln in lanes:
                 cur.wait_stream(ln)
 
-        # ---- optional hipGraph of one trip round the ring --------------------------
+        # ---- hipGraphs: the K-step region (and the W warm-up steps) are captured whole -------------
+        # One replay = up to kGraphSteps consecutive steps (a longer region is replayed in pieces): with several
+        # streams every replay forks and joins its branches once, ~18 us, which a graph of only one trip round
+        # the ring (8 steps) does not amortise (tools/ubench/headline_abl.hip: 13.3 us per step against 12.0 us for
+        # 64 steps per replay and 11.1 us free-running).
+        kGraphSteps = 512
+        graphs = {}
+
+        def graph_for(n):
+            if n not in graphs:
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    trip(n)
+                graphs[n] = g
+            return graphs[n]
+
         graph = None
         if not a.no_graph:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                trip(a.ring)
+                trip(a.ring)                         # warm-up off the capture: lazy initialisations
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                trip(a.ring)
-
-        # K or W need not be multiples of the ring: the remainder steps get their own captured graph
-        # (an eager launch costs tens of microseconds of Python per step, several times the kernel)
-        rem_graphs = {}
-        if graph is not None:
-            for rem in sorted({a.steps % a.ring, a.warmup % a.ring} - {0}):
-                torch.cuda.synchronize()
-                gr = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gr):
-                    trip(rem)
-                rem_graphs[rem] = gr
+            for k in (a.warmup, a.steps):
+                full, rem = divmod(k, kGraphSteps)
+                if full:
+                    graph_for(kGraphSteps)
+                if rem:
+                    graph_for(rem)
+            graph = True
 
         def run(k):
             if graph is not None:
-                full, rem = divmod(k, a.ring)
+                full, rem = divmod(k, kGraphSteps)
                 for _ in range(full):
-                    graph.replay()
-                if rem in rem_graphs:
-                    rem_graphs[rem].replay()
-                else:
-                    trip(rem)
+                    graphs[kGraphSteps].replay()
+                if rem:
+                    graphs[rem].replay()
             else:
                 full, rem = divmod(k, a.ring)
                 for _ in range(full):

@@ -24,6 +24,7 @@ int main(int argc, char **argv)
     // argv[2] = number of streams: batch i runs on stream i % NS and evaluates the params of batch i + NS, so
     // that consecutive launches (independent batches) may overlap their ramp and tail
     const int NS = argc > 2 ? atoi(argv[2]) : 1;
+    const int GRAPH = argc > 3 ? atoi(argv[3]) : 0;     // > 0: replay a captured graph of GRAPH trips round the ring
     hipStream_t streams[4];
     for (int i = 0; i < NS; ++i) CK(hipStreamCreate(&streams[i]));
     double *tab; CK(hipMalloc(&tab, 3 * N * sizeof(double)));
@@ -85,10 +86,34 @@ int main(int argc, char **argv)
             }
             for (int i = 0; i < 2 * RING; ++i) step(i);
             CK(hipDeviceSynchronize());
-            CK(hipEventRecord(e0));
-            for (int i = 0; i < ITERS; ++i) step(i);
-            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
-            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            float ms;
+            if (GRAPH && NS > 1) {
+                // one trip round the ring captured as a graph with NS parallel branches (fork / join by events)
+                hipGraph_t g; hipGraphExec_t ge;
+                hipEvent_t fork, join[4];
+                CK(hipEventCreate(&fork));
+                for (int k = 0; k < NS; ++k) CK(hipEventCreate(&join[k]));
+                CK(hipStreamBeginCapture(streams[0], hipStreamCaptureModeGlobal));
+                CK(hipEventRecord(fork, streams[0]));
+                for (int k = 1; k < NS; ++k) CK(hipStreamWaitEvent(streams[k], fork, 0));
+                for (int i = 0; i < GRAPH * RING; ++i) step(i);
+                for (int k = 1; k < NS; ++k) { CK(hipEventRecord(join[k], streams[k])); CK(hipStreamWaitEvent(streams[0], join[k], 0)); }
+                CK(hipStreamEndCapture(streams[0], &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                for (int r = 0; r < 3; ++r) CK(hipGraphLaunch(ge, streams[0]));
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, streams[0]));
+                const int reps = ITERS / (GRAPH * RING);
+                for (int r = 0; r < reps; ++r) CK(hipGraphLaunch(ge, streams[0]));
+                CK(hipEventRecord(e1, streams[0])); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                ms = ms * ITERS / (reps * GRAPH * RING);
+            } else {
+                CK(hipEventRecord(e0));
+                for (int i = 0; i < ITERS; ++i) step(i);
+                CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+            }
             const double us = ms / ITERS * 1e3;
             printf("dets/sample %2d  %-34s %7.2f us  %6.0f GB/s (%.0f B/pt)\n", ndet, name, us,
                    bytes_per_pt * B * N / (us * 1e-6) / 1e9, bytes_per_pt);
