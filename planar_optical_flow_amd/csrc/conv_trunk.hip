@@ -194,6 +194,168 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
         }
 }
 
+// ---- split-K form for small launches (streaming inference: one scan per call) -------------------------
+// With a few hundred column tiles the layer cannot give every SIMD a wave even at 32 output channels per
+// workgroup, and a wave that owns a whole K loop (up to 768 dependent k-steps) runs at a quarter of the MFMA
+// issue rate: nothing else is resident to hide its LDS / load latency (86-92 us per layer against an 18 us issue
+// bound, profiles/r1i_conv_small_*).  Here the FOUR WAVES OF A WORKGROUP SHARE ONE 32-COLUMN TILE AND SPLIT K:
+// wave w takes a contiguous quarter of the channel chunks, stages its own weight chunks in a private LDS
+// region (no workgroup barrier inside the loop), and the four partial accumulators meet in LDS at the end,
+// summed in wave order by wave 0, which runs the epilogue.  Four times the workgroups, a quarter of the
+// serial chain.  (Summation order differs from conv3_kernel; exact on integer data, deterministic.)
+template <int CT>
+__global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_splitk_kernel(ConvArgs a)
+{
+    constexpr int COG = 32 * CT;
+    constexpr int NP = kCvCC / 2;
+    constexpr int WV = (kCvRows * COG / 4 + 63) / 64;           // float4 groups per lane and chunk
+    __shared__ __attribute__((aligned(16))) float s_w[kCvWaves][2][kCvRows][COG];
+    __shared__ __attribute__((aligned(16))) float s_acc[kCvWaves - 1][CT * 16][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int co0 = blockIdx.y * COG;
+    const long long ncol = (long long)a.S * a.L;
+    const long long n_g = (long long)blockIdx.x * 32 + r;        // every wave of the workgroup: the same column
+    const bool col_ok = n_g < ncol;
+    const long long nc = col_ok ? n_g : ncol - 1;
+    const int seq = (int)(nc / a.L), l = (int)(nc - (long long)seq * a.L);
+    const bool tap_ok[3] = {col_ok && l > 0, col_ok, col_ok && l < a.L - 1};
+    const unsigned base_off = (unsigned)((long long)seq * a.Ci * a.L + l);
+    unsigned off_h[3], off_0[3];
+#pragma unroll
+    for (int tap = 0; tap < 3; ++tap) {
+        off_0[tap] = (base_off + (tap_ok[tap] ? tap - 1 : 0)) * 4u;
+        off_h[tap] = off_0[tap] + (unsigned)(h * a.L) * 4u;
+    }
+    const int nchunk = (a.Ci + kCvCC - 1) / kCvCC;
+    const int per = (nchunk + kCvWaves - 1) / kCvWaves;
+    const int ch_lo = min(wave * per, nchunk), ch_hi = min(ch_lo + per, nchunk);
+
+    using F4V = float __attribute__((ext_vector_type(4)));
+    F4V wreg[WV];
+    unsigned woff[WV];
+    int wcl[WV];
+    const bool wvec = (a.Co & 3) == 0;
+#pragma unroll
+    for (int q = 0; q < WV; ++q) {
+        const int e4 = lane + q * 64;
+        const int row = e4 / (COG / 4), c = (e4 - row * (COG / 4)) * 4;
+        const int tap = row / kCvCC, cl = row - tap * kCvCC;
+        const bool in = e4 < kCvRows * COG / 4 && co0 + c < a.Co;
+        woff[q] = in ? (unsigned)(((long long)tap * a.Ci + cl) * a.Co + c) * 4u : 0u;
+        wcl[q] = in ? cl : kCvCC;
+    }
+    auto load_w = [&](int ci0) {
+        const int cc = min(kCvCC, a.Ci - ci0);
+        const char *wbase = reinterpret_cast<const char *>(a.wt + (long long)ci0 * a.Co + co0);
+#pragma unroll
+        for (int q = 0; q < WV; ++q) {
+            F4V v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (wcl[q] < cc) {
+                if (wvec) {
+                    v = *reinterpret_cast<const F4V *>(wbase + woff[q]);
+                } else {
+                    const float *pw = reinterpret_cast<const float *>(wbase + woff[q]);
+                    const int e4 = lane + q * 64;
+                    const int c = (e4 % (COG / 4)) * 4;
+                    for (int j = 0; j < 4; ++j) v[j] = (co0 + c + j < a.Co) ? pw[j] : 0.0f;
+                }
+            }
+            wreg[q] = v;
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < WV; ++q) {
+            const int e4 = lane + q * 64;
+            if (e4 < kCvRows * COG / 4) reinterpret_cast<F4V *>(&s_w[wave][buf][0][0])[e4] = wreg[q];
+        }
+    };
+    float xb[2][3][NP];
+    auto load_x = [&](int set, int ci0) {
+        const int cc = min(kCvCC, a.Ci - ci0);
+#pragma unroll
+        for (int tap = 0; tap < 3; ++tap)
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int c2 = min(2 * p, cc - 1);
+                const char *rowp = reinterpret_cast<const char *>(a.x + (long long)(ci0 + c2) * a.L);
+                const bool pair = 2 * p + 1 < cc;
+                xb[set][tap][p] = *reinterpret_cast<const float *>(rowp + (pair ? off_h[tap] : off_0[tap]));
+            }
+    };
+
+    f32x16 acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) acc[t] = f32x16{0};
+
+    if (ch_lo < ch_hi) {
+        load_w(ch_lo * kCvCC);
+        load_x(0, ch_lo * kCvCC);
+        store_w(0);
+    }
+    auto chunk = [&](auto set_tag, const int ch) {
+        constexpr int SET = decltype(set_tag)::value;
+        const int ci0 = ch * kCvCC;
+        const int cc = min(kCvCC, a.Ci - ci0);
+        const bool more = ch + 1 < ch_hi;
+        if (more) {
+            load_w(ci0 + kCvCC);
+            load_x(SET ^ 1, ci0 + kCvCC);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 3 * NP; ++ks) {
+            const int tap = ks / NP, p = ks - tap * NP;
+            float a_cur[CT];
+#pragma unroll
+            for (int t = 0; t < CT; ++t) a_cur[t] = s_w[wave][SET][tap * kCvCC + 2 * p + h][t * 32 + r];
+            const bool ok = tap_ok[tap] && (2 * p + h < cc);
+            const float bv = ok ? xb[SET][tap][p] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bv, acc[t], 0, 0, 0);
+        }
+        if (more) store_w(SET ^ 1);       // the wave's own region: LDS operations of one wave stay in order
+    };
+    for (int ch = ch_lo; ch < ch_hi; ch += 2) {
+        chunk(std::integral_constant<int, 0>{}, ch);
+        if (ch + 1 < ch_hi) chunk(std::integral_constant<int, 1>{}, ch + 1);
+    }
+    // partial sums of waves 1..3 -> LDS, wave 0 adds them in wave order
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) s_acc[wave - 1][t * 16 + reg][lane] = acc[t][reg];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < kCvWaves - 1; ++w)
+#pragma unroll
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[t][reg] += s_acc[w][t * 16 + reg][lane];
+    const int Lout = a.pool ? a.L / 2 : a.L;
+    float *os = a.out + (long long)seq * a.Co * Lout + (a.pool ? l / 2 : l);
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int co = co0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+            const bool co_ok = co < a.Co;
+            const int cs = co_ok ? co : a.Co - 1;
+            float y = acc[t][reg] * a.scale[cs] + a.shift[cs];
+            y = y > 0.0f ? y : y * a.slope;
+            if (a.pool) {
+                const float other = __shfl_xor(y, 1, 64);
+                y = fmaxf(y, other);
+                if (col_ok && co_ok && !(l & 1) && l + 1 < a.L) os[(long long)co * Lout] = y;
+            } else {
+                if (col_ok && co_ok) os[(long long)co * Lout] = y;
+            }
+        }
+}
+
 }  // namespace
 
 extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
@@ -228,10 +390,23 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
         // summation order, bit-identical results
         int ct = Co <= 64 ? 2 : 4;
         while (ct > 1 && gx * ((Co + 32 * ct - 1) / (32 * ct)) < kCvFillWorkgroups) ct >>= 1;
-        const dim3 grid((unsigned)gx, (Co + 32 * ct - 1) / (32 * ct));
-        if (ct == 1) conv3_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
-        else if (ct == 2) conv3_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
-        else conv3_kernel<4><<<grid, 64 * kCvWaves, 0, s>>>(a);
+        const long long wgs = gx * ((Co + 32 * ct - 1) / (32 * ct));
+        const int nchunk = (Ci + kCvCC - 1) / kCvCC;
+        if (wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves && tiles <= 0x7fffffffLL) {
+            // still a launch that leaves most SIMDs with at most one wave, and a K loop long enough to pay for
+            // the reduction (Ci >= 128; measured at one scan per call: 512->256 L=7 92 -> 58 us, 256->128 L=7
+            // 43 -> 19 us, 256->256 L=14 52 -> 45 us; the widening layers Co = 2 Ci and Ci = 64 lose 10-50 %
+            // to it and keep the one-wave-per-tile form): split K over the workgroup's waves
+            const int cts = ct > 2 ? 2 : ct;                      // the partial sums go through LDS: 32 or 64 channels
+            const dim3 grid((unsigned)tiles, (Co + 32 * cts - 1) / (32 * cts));
+            if (cts == 1) conv3_splitk_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
+            else conv3_splitk_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
+        } else {
+            const dim3 grid((unsigned)gx, (Co + 32 * ct - 1) / (32 * ct));
+            if (ct == 1) conv3_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
+            else if (ct == 2) conv3_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
+            else conv3_kernel<4><<<grid, 64 * kCvWaves, 0, s>>>(a);
+        }
         POF_CHECK_LAUNCH();
     }
     return POF_OK;
