@@ -40,6 +40,50 @@ struct ConvArgs {
     float slope;
 };
 
+// Epilogue shared by both kernels.  C/D layout of v_mfma_f32_32x32x2_f32: column n = lane & 31,
+// output channel = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5) inside a 32-channel tile.
+//   y = acc * scale[co] + shift[co] (BatchNorm folded with the conv bias; the two vectors of the workgroup's
+//   channel tile sit in LDS, four consecutive channels per 16-byte read), LeakyReLU as max(y, slope * y) for
+//   0 <= slope <= 1, the pooled pair on adjacent lanes through one DPP move, stores as uniform base + 32-bit
+//   offset.  (The first version did two global loads, a 64-bit multiply-add, a select chain and a
+//   ds_bpermute per output: ~1300 vector instructions per wave, 8 % of a 128 -> 128 layer.)
+template <int CT>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[CT], const float *s_scale,
+                                              const float *s_shift, int co0, int seq, int l, int h, bool col_ok)
+{
+    const int Lout = a.pool ? a.L / 2 : a.L;
+    const bool slope01 = a.slope >= 0.0f && a.slope <= 1.0f;                          // uniform
+    const long long obase = (long long)seq * a.Co * Lout + (a.pool ? l / 2 : l);      // element offset of (seq, co = 0, l)
+    const bool small = (long long)a.S * a.Co * Lout < (1LL << 30);                    // uniform: 32-bit byte offsets
+    const bool writer = col_ok && (!a.pool || (!(l & 1) && l + 1 < a.L));
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const bool tile_full = co0 + t * 32 + 31 < a.Co;                               // uniform
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int cl = t * 32 + 8 * g + 4 * h;                                     // first of 4 consecutive channels
+            const float4 sc = *reinterpret_cast<const float4 *>(s_scale + cl);
+            const float4 sh = *reinterpret_cast<const float4 *>(s_shift + cl);
+            const float scv[4] = {sc.x, sc.y, sc.z, sc.w}, shv[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = acc[t][4 * g + j] * scv[j] + shv[j];
+                y = slope01 ? fmaxf(y, y * a.slope) : (y > 0.0f ? y : y * a.slope);
+                if (a.pool) {
+                    // the pair (2j, 2j+1) sits on adjacent lanes: quad_perm [1,0,3,2]
+                    const float other = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, y), 0xB1, 0xF, 0xF, true));
+                    y = fmaxf(y, other);
+                }
+                const int co = co0 + cl + j;
+                if (writer && (tile_full || co < a.Co)) {
+                    if (small) a.out[(unsigned)(obase + (long long)co * Lout)] = y;
+                    else a.out[obase + (long long)co * Lout] = y;
+                }
+            }
+        }
+    }
+}
+
 template <int CT>
 __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
 {
@@ -47,9 +91,15 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
     constexpr int NT = 64 * kCvWaves;
     constexpr int NP = kCvCC / 2;                      // channel pairs (k-steps) per tap and chunk
     __shared__ __attribute__((aligned(16))) float s_w[2][kCvRows][COG];   // double-buffered weight chunk
+    __shared__ __attribute__((aligned(16))) float s_scale[COG], s_shift[COG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const int co0 = blockIdx.y * COG;
+    if (threadIdx.x < COG) {      // visible to every wave after the first barrier of the K loop
+        const int cs = min(co0 + (int)threadIdx.x, a.Co - 1);
+        s_scale[threadIdx.x] = a.scale[cs];
+        s_shift[threadIdx.x] = a.shift[cs];
+    }
     const long long ncol = (long long)a.S * a.L;
     const long long n_g = ((long long)blockIdx.x * kCvWaves + wave) * 32 + r;   // this lane's column
     const bool col_ok = n_g < ncol;
@@ -172,26 +222,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
         chunk(std::integral_constant<int, 0>{}, ch);
         if (ch + 1 < nchunk) chunk(std::integral_constant<int, 1>{}, ch + 1);
     }
-    // epilogue.  C/D layout: col = lane & 31 (column n), row = (reg & 3) + 8 * (reg >> 2) + 4 * h (co)
-    const int Lout = a.pool ? a.L / 2 : a.L;
-    float *os = a.out + (long long)seq * a.Co * Lout + (a.pool ? l / 2 : l);
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = co0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const bool co_ok = co < a.Co;
-            const int cs = co_ok ? co : a.Co - 1;
-            float y = acc[t][reg] * a.scale[cs] + a.shift[cs];
-            y = y > 0.0f ? y : y * a.slope;
-            if (a.pool) {
-                const float other = __shfl_xor(y, 1, 64);       // the pair (2j, 2j+1) sits on adjacent lanes
-                y = fmaxf(y, other);
-                if (col_ok && co_ok && !(l & 1) && l + 1 < a.L) os[(long long)co * Lout] = y;
-            } else {
-                if (col_ok && co_ok) os[(long long)co * Lout] = y;
-            }
-        }
+    conv_epilogue<CT>(a, acc, s_scale, s_shift, co0, seq, l, h, col_ok);
 }
 
 // ---- split-K form for small launches (streaming inference: one scan per call) -------------------------
@@ -211,9 +242,15 @@ __global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_splitk_kernel(ConvArgs
     constexpr int WV = (kCvRows * COG / 4 + 63) / 64;           // float4 groups per lane and chunk
     __shared__ __attribute__((aligned(16))) float s_w[kCvWaves][2][kCvRows][COG];
     __shared__ __attribute__((aligned(16))) float s_acc[kCvWaves - 1][CT * 16][64];
+    __shared__ __attribute__((aligned(16))) float s_scale[COG], s_shift[COG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
     const int co0 = blockIdx.y * COG;
+    if (threadIdx.x < COG) {      // visible to wave 0 after the barrier in front of the reduction
+        const int cs = min(co0 + (int)threadIdx.x, a.Co - 1);
+        s_scale[threadIdx.x] = a.scale[cs];
+        s_shift[threadIdx.x] = a.shift[cs];
+    }
     const long long ncol = (long long)a.S * a.L;
     const long long n_g = (long long)blockIdx.x * 32 + r;        // every wave of the workgroup: the same column
     const bool col_ok = n_g < ncol;
@@ -335,25 +372,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_splitk_kernel(ConvArgs
         for (int t = 0; t < CT; ++t)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) acc[t][reg] += s_acc[w][t * 16 + reg][lane];
-    const int Lout = a.pool ? a.L / 2 : a.L;
-    float *os = a.out + (long long)seq * a.Co * Lout + (a.pool ? l / 2 : l);
-#pragma unroll
-    for (int t = 0; t < CT; ++t)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = co0 + t * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
-            const bool co_ok = co < a.Co;
-            const int cs = co_ok ? co : a.Co - 1;
-            float y = acc[t][reg] * a.scale[cs] + a.shift[cs];
-            y = y > 0.0f ? y : y * a.slope;
-            if (a.pool) {
-                const float other = __shfl_xor(y, 1, 64);
-                y = fmaxf(y, other);
-                if (col_ok && co_ok && !(l & 1) && l + 1 < a.L) os[(long long)co * Lout] = y;
-            } else {
-                if (col_ok && co_ok) os[(long long)co * Lout] = y;
-            }
-        }
+    conv_epilogue<CT>(a, acc, s_scale, s_shift, co0, seq, l, h, col_ok);
 }
 
 }  // namespace
