@@ -90,7 +90,7 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    path = path or LIB_PATH
+    path = path or os.environ.get("POF_LIB_PATH") or LIB_PATH      # POF_LIB_PATH: experimental builds (tools/)
     # torch must be imported BEFORE the library is dlopen'ed: PyTorch-ROCm ships its own
     # libamdhip64, and the process has to end up with ONE HIP runtime -- the one that owns
     # torch's devices and streams.  Loaded the other way round, libpof_hip.so binds to the

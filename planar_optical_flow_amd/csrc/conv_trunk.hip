@@ -216,7 +216,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
             for (int t = 0; t < CT; ++t) a_cur[t] = a_nxt[t];
         }
         if (more) store_w(SET ^ 1);
-        __syncthreads();
+        __syncthreads();      // (measured: the per-chunk barriers cost 1 % of the trunk)
     };
     for (int ch = 0; ch < nchunk; ch += 2) {
         chunk(std::integral_constant<int, 0>{}, ch);
