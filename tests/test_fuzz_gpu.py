@@ -87,6 +87,73 @@ def test_fuzz_scan_preprocess(ops, seed):
         assert np.array_equal(out["dyn_mask"][b].cpu().numpy().astype(np.float64), dyn), (seed, b)
 
 
+@pytest.mark.parametrize("seed", range(14 * _SCALE))
+def test_fuzz_scan_preprocess_float32_flat_form(ops, seed):
+    """The flat-axis kernel (N >= 256, even) with FLOAT32 outputs -- the instantiation bench.py times: chunk
+    boundaries that fall inside samples (N not a multiple of 256), partial last chunks (odd batch sizes), crowded
+    samples (more than 8 detections: CSR path), every flow kind, chained launches whose next batch has a different
+    size.  Association, labels and masks are bit-exact; target_reg <= 1e-6; flow EPE <= 1e-5 m (float32 arithmetic;
+    kind 1 keeps float64); xy within float32 rounding."""
+    rng = np.random.default_rng(9000 + seed)
+    N = int(rng.choice([256, 258, 450, 512, 900, 3600]))
+    B = int(rng.integers(1, 60))
+    inc = float(rng.choice([0.5, 0.25, 0.1]))
+    sb = synth.make_batch(seed=9100 + seed, B=B, T=2, N=N, angle_inc=np.radians(inc),
+                          max_legs=int(rng.choice([0, 3, 6, 14])), mixed_classes=bool(rng.integers(0, 2)))
+    o, r, c = sb.det_csr()
+    det = ops.DetCSR.from_numpy(o, r, c, "cuda")
+    tab = ops.phi_table(np.radians(inc), N)
+    phi = R.laser_phi(np.radians(inc), N)
+    kind = int(rng.choice([ops.FLOW_DISPLACEMENT, ops.FLOW_DISPLACEMENT, ops.FLOW_TARGET, ops.FLOW_VELOCITY]))
+    canonical = bool(rng.integers(0, 2))
+    want = ("xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "valid_mask", "exclude_mask")
+    scans, o0, o1 = dev(sb.scans), dev(sb.odom0), dev(sb.odom1)
+    if seed % 2:
+        # chained form: params of this batch from a priming launch, params of a (different-size) next batch ride along
+        nb = synth.make_batch(seed=9200 + seed, B=int(rng.integers(1, 30)), T=2, N=N, angle_inc=np.radians(inc))
+        no, nr, nc = nb.det_csr()
+        ndet = ops.DetCSR.from_numpy(no, nr, nc, "cuda")
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, det.rphi.shape[0]), dtype=torch.uint8, device="cuda")
+        nws = torch.empty(ops.scan_preprocess_workspace_bytes(len(nb.scans), ndet.rphi.shape[0]), dtype=torch.uint8, device="cuda")
+        ops.scan_preprocess(scans, tab, o0, o1, det, flow_kind=kind, canonical=canonical, want=want, workspace=ws, phases=1)
+        out = ops.scan_preprocess(scans, tab, o0, o1, det, flow_kind=kind, canonical=canonical, want=want, workspace=ws,
+                                  next_batch={"odom0": dev(nb.odom0), "odom1": dev(nb.odom1), "dets": ndet, "workspace": nws})
+        # the params the launch left for the next batch give the same result as a self-contained call
+        a_ = ops.scan_preprocess(dev(nb.scans), tab, dev(nb.odom0), dev(nb.odom1), ndet, flow_kind=kind, canonical=canonical,
+                                 want=("flow", "target_cls"), workspace=nws, phases=2)
+        b_ = ops.scan_preprocess(dev(nb.scans), tab, dev(nb.odom0), dev(nb.odom1), ndet, flow_kind=kind, canonical=canonical,
+                                 want=("flow", "target_cls"))
+        assert torch.equal(a_["flow"], b_["flow"]) and torch.equal(a_["target_cls"], b_["target_cls"])
+    else:
+        out = ops.scan_preprocess(scans, tab, o0, o1, det, flow_kind=kind, canonical=canonical, want=want)
+    assert out["flow"].dtype == torch.float32 and out["xy"].dtype == torch.float32
+    ref_flow = {ops.FLOW_DISPLACEMENT: R.displacement_from_odometry, ops.FLOW_VELOCITY: R.velocity_from_odometry}
+    epes = []
+    for b in range(B):
+        cur = sb.scans[b, -1]
+        d = sb.dets[b]
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        if kind == ops.FLOW_TARGET:
+            flow = R.flow_target(cur, phi, sb.odom0[b], sb.odom1[b])
+        else:
+            flow = ref_flow[kind](xy, sb.odom0[b], sb.odom1[b])
+        if canonical:
+            flow = R.flow_to_canonical(flow, phi)
+        epes.append(np.linalg.norm(out["flow"][b].cpu().numpy().astype(np.float64) - flow, axis=-1).mean())
+        np.testing.assert_allclose(out["xy"][b].cpu().numpy(), xy, rtol=2e-7, atol=1e-7)
+        cls, reg = R.regression_target(cur, phi, d["wc"], d["wa"], d["wp"])
+        assert np.array_equal(out["target_cls"][b].cpu().numpy(), cls), (seed, b)
+        radii = [0.6] * len(d["wc"]) + [0.4] * len(d["wa"]) + [0.35] * len(d["wp"])
+        dets = list(d["wc"]) + list(d["wa"]) + list(d["wp"])
+        assert np.array_equal(out["closest"][b].cpu().numpy(), np.asarray(R.closest_detection(cur, phi, dets, radii))), (seed, b)
+        np.testing.assert_allclose(out["target_reg"][b].cpu().numpy(), reg, rtol=0, atol=1e-6)
+        dyn, val = R.dynamic_mask(xy, d["wc"], d["wa"], d["wp"]), R.valid_point_mask(cur)
+        assert np.array_equal(out["dyn_mask"][b].cpu().numpy().astype(np.float64), dyn), (seed, b)
+        assert np.array_equal(out["valid_mask"][b].cpu().numpy(), val)
+        assert np.array_equal(out["exclude_mask"][b].cpu().numpy().astype(np.float64), dyn * val)
+    assert max(epes) < 1e-5, (seed, kind, max(epes))
+
+
 @pytest.mark.parametrize("seed", range(12 * _SCALE))
 def test_fuzz_attention_and_correlation(ops, seed):
     rng = np.random.default_rng(5000 + seed)
