@@ -396,6 +396,8 @@ def main():
         ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
 
+    box = None if a.no_extra else bench_box_head(dev, world, rank, backend, barrier)      # all ranks: it holds collectives
+
     result = None
     if rank == 0:
         # algorithmic bytes per scan: 4N range row in; out 8N flow f32 +
@@ -462,6 +464,8 @@ def main():
                                        "note": "the same K steps, one launch at a time on one stream"}
         if strong is not None:
             result["strong_scaling"] = strong
+        if box is not None:
+            result["box_head_train"] = box
         if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line
             result["host_fed"] = bench_host_fed(ops, sb, tab, dev)
             result["cutout"] = bench_cutout(ops, synth, tab, dev, variants=not a.no_model)
@@ -485,6 +489,71 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
+    """BASELINE configs[3]: one optimisation step of the box-regression head (train_box_regression_1.yaml: PointNet
+    on 64-point segments, batch 256 PER RANK, Adam with amsgrad), batch-sharded: forward + backward, ONE flat
+    gradient all-reduce over RCCL (dist.GradientAllReduce, 3.8 MB) between backward and the optimiser step,
+    BatchNorm statistics over the global batch (dist.SyncBatchNorm1d).  Runs on every rank (it contains the
+    collectives); rank 0 reports.  Also times the gradient all-reduce on its own."""
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(REPO, "planar_optical_flow_amd"))
+    from planar_optical_flow_amd import dist as pdist
+    from src.model.get_model import get_model
+    from src.pipeline.optim import Optim
+    torch.manual_seed(4)
+    model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).to(dev)
+    if world > 1:
+        pdist.broadcast_parameters(model)
+        pdist.convert_sync_batchnorm(model)
+    model.train()
+    optim = Optim(model, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
+    reducer = pdist.GradientAllReduce(model)
+    g = torch.Generator(device=dev).manual_seed(40 + rank)
+    per = 256
+    x = torch.randn((per, 64, 3), device=dev, generator=g) * 0.3
+    y = torch.randn((per, 3), device=dev, generator=g) * 0.3
+
+    def step():
+        optim.zero_grad()
+        optim.set_lr(0)
+        loss = model.loss_fn(model(x), y)
+        loss.backward()
+        reducer()
+        optim.step()
+        return loss
+
+    for _ in range(warm):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = (time.perf_counter() - t0) / steps
+    ar_ms = None
+    if world > 1:
+        for _ in range(3):
+            reducer()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            reducer()
+        barrier()
+        ar_ms = (time.perf_counter() - t0) / 20 * 1e3
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    nbytes = reducer.bucket.numel() * 4
+    return {"workload": "BASELINE configs[3]: box-regression head training step, batch 256 per rank x %d rank(s), "
+                        "64-point segments, Adam(amsgrad), one flat gradient all-reduce, global-batch BatchNorm" % world,
+            "ms_per_step": dt * 1e3, "samples_per_s": world * per / dt, "per_rank_batch": per,
+            "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": nbytes,
+            "grad_allreduce_busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if ar_ms else None,
+            "collective_backend": backend if world > 1 else None}
 
 
 def bench_host_fed(ops, sb, tab, dev, steps=200):

@@ -780,6 +780,9 @@ def _check_two_rank_line(d):
     st = d["strong_scaling"]                                   # one 4096-scan batch cut in two
     assert st["scans_per_rank_per_step"] == 2048 and st["global_batch"] == 4096 and st["value"] > 0
     assert d["config"]["collective_backend"] == "gloo" and d["config"]["rccl_ranks"] is None
+    bh = d["box_head_train"]                                   # BASELINE configs[3]: the one path with a collective
+    assert bh["per_rank_batch"] == 256 and bh["samples_per_s"] > 0 and bh["grad_allreduce_ms"] > 0
+    assert bh["grad_bucket_bytes"] == 4 * 953219 and bh["collective_backend"] == "gloo"
 
 
 def test_bench_plain_command_line_starts_its_own_ranks():
@@ -822,6 +825,8 @@ def test_bench_single_gpu_line_and_world_size_check():
     assert cb["kind"] == "port" and cb["repeats"] >= 3 and cb["cores"] == min(cb["host"]["physical_cores"], cb["host"]["usable_cpus"])
     assert cb["single_process_scans_per_s"] > 0 and cb["min"] <= cb["value"] <= cb["max"]
     assert 0 < d["host_fed"]["host_fed_scans_per_s"] < d["value"]
+    assert d["box_head_train"]["grad_allreduce_ms"] is None and d["box_head_train"]["samples_per_s"] > 0
+    assert d["single_stream"]["ms_per_step"] >= d["ms_per_step"] * 0.95 and d["roofline"]["concurrent_launches"] == 4
     assert set(d["small_kernels"]) >= {"segment_kernel", "nms_kernel", "rotate_iou_kernel", "flow_errors_kernel",
                                        "gather_windows_kernel", "segment_inputs_kernel"}
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
