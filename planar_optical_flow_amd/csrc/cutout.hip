@@ -146,7 +146,9 @@ __host__ __device__ inline size_t win_table_bytes(int cap) { return ((size_t)cap
 template <int VMODE>
 __device__ __forceinline__ float finish_value(const CutArgs &a, double ct, double dd)
 {
-    if (VMODE == 1) return (float)((ct - dd) * a.rdepth);
+    // VMODE 1: 1/depth is a power of two: scaling by it commutes with the rounding to float32 (no overflow /
+    // underflow at these magnitudes), so the float64 multiply becomes a float32 one
+    if (VMODE == 1) return (float)(ct - dd) * a.rdepth_f32;
     if (a.centered) {
         ct = ct - dd;
         ct = a.depth_pow2 ? ct * a.rdepth : pof_div_const(ct, a.depth, a.rdepth);
@@ -191,6 +193,10 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     const int PA = s_area * P;
     constexpr bool LDSROWS = LDSMODE == 1;
     __shared__ int s_span_lo, s_span_hi, s_acount;
+    // k as float64, k < 64: phase B reads its eight k values per lane from here (two per 16-byte LDS read) instead
+    // of forming them with eight float64 additions
+    __shared__ __align__(16) double s_kd[64];
+    if (threadIdx.x < 64) s_kd[threadIdx.x] = (double)threadIdx.x;
     if (threadIdx.x == 0) {
         s_span_lo = N;
         s_span_hi = -1;
@@ -370,9 +376,21 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
                 ratio[u] = rf;
             }
         } else {
+            double kdv[KV];
+            if (P4 > 0) {
+#pragma unroll
+                for (int u = 0; u < KV; u += 2) {
+                    const double2 t2 = *reinterpret_cast<const double2 *>(&s_kd[k0 + u]);   // k0 is a multiple of 8
+                    kdv[u] = t2.x;
+                    kdv[(u + 1) % KV] = t2.y;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < KV; ++u) kdv[u] = kd0 + (double)u;
+            }
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
-                const double idx = frac_index(a0, step, kd0 + (double)u, phi0, dphi, rdphi);
+                const double idx = frac_index(a0, step, kdv[u], phi0, dphi, rdphi);
                 // in range trunc == floor and fract(idx) == idx - floor(idx) exactly; out of
                 // range the value is replaced by the padding, only the address must stay legal
                 lo[u] = FULL ? (int)idx : min(max((int)idx, 0), N - 1);
