@@ -729,6 +729,14 @@ def bench_small_kernels(ops, synth, tab, dev):
     ms = _time_kernel(torch, lambda: ops.gather_windows(store, first, idx, T), 20)
     row("gather_windows_kernel", ms, B * (T + 1) * N * 8,
         "N1: %d windows of %d + 1 rows x %d points, read + write" % (B, T, N))
+    # N4: polar TSDF grid (pure write stream)
+    Bp, Tp, Rp = 2048, 5, 31
+    sbp = synth.make_batch(seed=3, B=Bp, T=Tp, N=N)
+    scp = torch.from_numpy(sbp.scans).to(dev)
+    outp = torch.empty((Bp, Tp, Rp, N), dtype=torch.float32, device=dev)
+    ms = _time_kernel(torch, lambda: ops.polar_grid(scp, out=outp), 20)
+    row("polar_grid_flat_kernel", ms, Bp * Tp * N * 4 * (Rp + 1),
+        "N4: %d x %d scan rows -> %d range bins each; aligned 16-byte non-temporal stores over the flat output" % (Bp, Tp, Rp))
     # N3: all detections of a frame in one launch
     Np, Sd = 4000, 64
     pts = torch.rand((Np, 2), dtype=torch.float64, device=dev, generator=g) * 10

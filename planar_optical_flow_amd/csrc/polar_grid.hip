@@ -8,8 +8,15 @@
 // (clip(r) - mid) / mag * 2 (float32 throughout, as NumPy >= 2 evaluates the reference).
 //
 // Pure write stream: T*N*4 bytes in, T*R*N*4 bytes out per sample (R = 31 by default).
-// One lane owns 4 consecutive points of one scan row and writes them for every range
-// bin with 16-byte streaming stores (each wave store = 1 KB contiguous).
+// polar_grid_flat_kernel (round 2): one workgroup per scan row.  The row's output block [R][N] is one contiguous
+// run of R*N floats; it is written as a FLAT stream of 16-byte, 16-byte-aligned non-temporal stores (a wave store =
+// 1 KB of whole cache lines) whatever N is -- the first version needed N % 4 == 0 for its 16-byte stores and
+// fell back to 4-byte stores at N = 450 (3.4 TB/s; aligned one-shot stores reach 6-6.9 TB/s on this part,
+// profiles/r2_store_ceiling.txt).  Per-point values (bin index g, hit value) and the 2R+1 possible TSDF values
+// clip((q - g) * bin) [/ mag * 2] are staged in LDS once per row, so an output element costs two LDS reads and
+// a select; (q, i) advance incrementally (no division per element).
+// polar_grid_kernel (rows that do not fit LDS): one lane owns 4 consecutive points of one scan row and writes
+// them for every range bin.
 #include "pof_common.h"
 
 namespace {
@@ -67,6 +74,69 @@ __global__ __launch_bounds__(kPolarThreads) void polar_grid_kernel(PolarArgs a)
     }
 }
 
+__global__ __launch_bounds__(256) void polar_grid_flat_kernel(PolarArgs a)
+{
+    extern __shared__ __align__(16) unsigned char psm[];
+    int *s_g = reinterpret_cast<int *>(psm);
+    float *s_val = reinterpret_cast<float *>(s_g + a.N);
+    float *s_t = s_val + a.N;                      // [2R + 1]: TSDF value of q - g = d at index d + R
+    const long long row = blockIdx.x;
+    const int N = a.N, R = a.R, tid = threadIdx.x;
+    const float *src = a.scans + row * N;
+    for (int i = tid; i < N; i += 256) {
+        // np.clip(NaN) stays NaN; fmin/fmax would drop it -> explicit compares
+        float r = src[i];
+        r = r < a.minr ? a.minr : r;
+        r = r > a.maxr ? a.maxr : r;
+        s_g[i] = (int)((r - a.minr) / a.bin);
+        s_val[i] = a.normalize ? (r - a.mid) / a.mag * 2.0f : r;
+    }
+    for (int d = tid; d < 2 * R + 1; d += 256) s_t[d] = cell(a, d - R, 0, 0.0f - 1.0f);   // q - g = d - R != 0 except d = R (unused)
+    __syncthreads();
+    const long long G0 = row * R * N;              // global element index of the block
+    float *blk = a.out + G0;
+    const int total = R * N;
+    // elements in front of the first 16-byte boundary (the block starts on a 4-byte boundary)
+    const int head = (int)(((16 - (reinterpret_cast<uintptr_t>(blk) & 15)) & 15) >> 2);
+    auto value = [&](int q, int i) -> float {
+        const int g = s_g[i];
+        return q == g ? s_val[i] : s_t[q - g + R];
+    };
+    if (tid < head && tid < total) blk[tid] = value(tid / N, tid % N);
+    const int nbody = total > head ? (total - head) >> 2 : 0;
+    const int tail0 = head + 4 * nbody;
+    if (tid < total - tail0) {
+        const int e = tail0 + tid;
+        blk[e] = value(e / N, e % N);
+    }
+    // 16-byte groups: group k = elements head + 4k ... ; lane strides by 256 groups = 1024 elements
+    int e = head + 4 * tid;
+    int q = e / N, i = e - q * N;
+    const int dq = 1024 / N, di = 1024 - dq * N;
+    using F4V = float __attribute__((ext_vector_type(4)));
+    for (int k = tid; k < nbody; k += 256) {
+        float v[4];
+        int qq = q, ii = i;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = value(qq, ii);
+            if (++ii == N) {
+                ii = 0;
+                ++qq;
+            }
+        }
+        const F4V o = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<F4V *>(blk + e));
+        e += 1024;
+        q += dq;
+        i += di;
+        if (i >= N) {
+            i -= N;
+            ++q;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pof_polar_grid(const float *scans, int B, int T, int N, double min_range, double max_range,
@@ -88,6 +158,19 @@ extern "C" int pof_polar_grid(const float *scans, int B, int T, int N, double mi
     const bool vec = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(scans) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     hipStream_t s = pof_stream(stream);
+    const size_t lds = (size_t)N * 8 + (size_t)(2 * a.R + 1) * 4;
+    if (lds <= 60 * 1024 && (long long)a.R * N < (1LL << 30) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        // flat form: one workgroup per scan row, aligned 16-byte stores for any N
+        for (long long r0 = 0; r0 < a.rows; r0 += 0x7fffffffLL) {
+            PolarArgs c = a;
+            const long long nr = a.rows - r0 < 0x7fffffffLL ? a.rows - r0 : 0x7fffffffLL;
+            c.scans = scans + r0 * N;
+            c.out = out + r0 * a.R * N;
+            polar_grid_flat_kernel<<<(unsigned)nr, 256, lds, s>>>(c);
+            POF_CHECK_LAUNCH();
+        }
+        return POF_OK;
+    }
     // grid.y <= 65535: rows beyond that go in further launches
     for (long long r0 = 0; r0 < a.rows; r0 += 65535) {
         PolarArgs c = a;
