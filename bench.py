@@ -737,6 +737,25 @@ def bench_small_kernels(ops, synth, tab, dev):
     ms = _time_kernel(torch, lambda: ops.polar_grid(scp, out=outp), 20)
     row("polar_grid_flat_kernel", ms, Bp * Tp * N * 4 * (Rp + 1),
         "N4: %d x %d scan rows -> %d range bins each; aligned 16-byte non-temporal stores over the flat output" % (Bp, Tp, Rp))
+    # N2 training tail: BatchNorm(train) + LeakyReLU + max-pool of one trunk unit at the reference's training
+    # batch (8 scans x 450 cutouts x 5 scans = 18 000 sequences, 128 channels x 48 points), forward and backward
+    Sb, Cb, Lb = 18000, 128, 48
+    yb = torch.randn((Sb, Cb, Lb), device=dev, generator=g)
+    gam = torch.rand(Cb, device=dev, generator=g) + 0.5
+    bet = torch.rand(Cb, device=dev, generator=g) - 0.5
+    rm, rv = torch.zeros(Cb, device=dev), torch.ones(Cb, device=dev)
+    zb, mu, istd = ops.bn_lrelu_pool_forward(yb, gam, bet, rm, rv, pool=True)
+    dzb = torch.randn(zb.shape, device=dev, generator=g)
+    el = Sb * Cb * Lb
+    ms = _time_kernel(torch, lambda: ops.bn_lrelu_pool_forward(yb, gam, bet, rm, rv, pool=True), 10)
+    row("bn_lrelu_pool_forward", ms, el * (4 + 4 + 2),
+        "N2 training tail, pooled unit: bn_stats (read y) + bn_apply (read y, write z/2): 10 B per element of y "
+        "[%d x %d x %d]" % (Sb, Cb, Lb))
+    ms = _time_kernel(torch, lambda: ops.bn_lrelu_pool_backward(yb, dzb, gam, bet, mu, istd, pool=True), 10)
+    row("bn_lrelu_pool_backward", ms, el * (4 + 2 + 4 + 2 + 4),
+        "N2 training tail backward: bn_bwd_reduce (read y, dz/2) + bn_bwd_dgrad (read y, dz/2, write dy): 16 B per "
+        "element")
+    del yb, zb, dzb
     # N3: all detections of a frame in one launch
     Np, Sd = 4000, 64
     pts = torch.rand((Np, 2), dtype=torch.float64, device=dev, generator=g) * 10

@@ -364,6 +364,29 @@ int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, cons
                        pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N2 trunk unit tail, training                  src/depracted/model/dr_spaam.py:8-19, :86-92
+ * z = max_pool1d?(LeakyReLU(BatchNorm1d_train(y)), 2) and its backward pass, for the
+ * convolution output y [S][C][L] float32 (L <= 256, C*L % 4 == 0, L even when pooled):
+ * out [S][C][pool ? L/2 : L].  Batch statistics over (S, L) in float64; running_mean /
+ * running_var (may be NULL) are updated with `momentum` as torch.nn.BatchNorm1d does
+ * (unbiased variance); save_mean / save_invstd [C] are what the backward pass needs
+ * besides y.  backward: dz [S][C][L or L/2] -> dy [S][C][L], dgamma [C], dbeta [C]; the
+ * pool routes a gradient to the first maximum of its pair (torch.max_pool1d).
+ * workspace: pof_bn_lrelu_pool_workspace_bytes(S, C, L) bytes (0 = unsupported shape).
+ * ---------------------------------------------------------------------- */
+size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L);
+int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const float *gamma,
+                              const float *beta, float *running_mean, float *running_var,
+                              double momentum, double eps, double negative_slope, int pool,
+                              float *out, float *save_mean, float *save_invstd, void *workspace,
+                              size_t workspace_bytes, pof_stream_t stream);
+int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
+                               const float *gamma, const float *beta, const float *save_mean,
+                               const float *save_invstd, double negative_slope, int pool, float *dy,
+                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                               pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105
  *                                                src/data_handle/jrdb_handle.py:178-256
  * points [Np][D] float64 (D = 2 or 3), centers [S][D], oris [S] -> per detection the

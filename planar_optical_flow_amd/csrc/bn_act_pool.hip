@@ -1,0 +1,416 @@
+// N2, training side: the BatchNorm1d(train) + LeakyReLU [+ max_pool1d(2)] tail of every trunk unit
+// (src/depracted/model/dr_spaam.py:8-19 `_conv`, :86-92 `_conv_and_pool`), forward and backward.
+//
+// The convolution itself stays library work in training (MIOpen's training solvers are good on these shapes);
+// what costs the time around it is the element-wise tail: at the reference's batch (8 scans x 450 cutouts x 5
+// scans = 18 000 sequences of 48 points) the framework's BatchNorm / LeakyReLU / max-pool kernels and their
+// backward passes take 17 ms of a 41 ms step (profiles/r2_train_step_kernel_stats.txt) -- sequences of 6..48
+// points are a poor fit for kernels written for image planes.  Here the tail is four streaming passes:
+//
+//   forward   bn_stats      read y                 -> per-(chunk, channel) sum / sum of squares (float64)
+//             bn_finalize   C workgroups           -> mean, 1/std, scale, shift, running statistics
+//             bn_apply      read y, write z        -> z = [pool](lrelu(y * scale + shift))
+//   backward  bn_bwd_reduce read y, dz             -> per-(chunk, channel) sum dU, sum dU * xhat
+//             bn_bwd_final  C workgroups           -> dgamma, dbeta, the two per-channel means
+//             bn_bwd_dgrad  read y, dz, write dy   -> dy = gamma / std * (dU - mean(dU) - xhat * mean(dU * xhat))
+//
+// with dU = (dz routed to the pool's winner) * lrelu'(u), u = y * scale + shift recomputed from y (nothing but y
+// and 2C floats is kept for the backward pass: no activation copy, no pool indices).
+//
+// Layout: y [S][C][L] float32 as the convolution wrote it.  One sample's [C][L] plane is P = C * L contiguous
+// floats; a lane owns 4 consecutive plane positions (one 16-byte load) and walks K samples, so its channel and
+// per-channel constants are fixed for the whole loop, a wave reads 1 KB runs, and the loads of successive
+// samples are independent.  A workgroup's plane slice is a whole number of channels (W = multiple of
+// lcm(L, 4) <= 1024 positions), so the statistics of a channel never straddle workgroups and the partial sums
+// are deterministic (no atomics).  HBM-bound: algorithmic bytes per element 4 (stats), 8 or 6 (apply),
+// 8 or 6 (reduce), 12 or 10 (dgrad) -- the second figure with pooling.
+#include "pof_common.h"
+
+namespace {
+
+constexpr int kBnThreads = 256;
+constexpr int kBnSlice = 4 * kBnThreads;      // plane positions per workgroup, at most
+
+struct BnGeo {
+    long long S;        // sequences
+    long long nchunk;   // sample chunks (grid.x)
+    int C, L, P;        // channels, points per sequence, P = C * L
+    int W;              // positions per plane slice (multiple of lcm(L, 4))
+    int K;              // samples per chunk
+    int nslice;         // grid.y
+};
+
+int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
+
+// K samples per workgroup: enough workgroups to fill the part several times over, few enough partial sums
+bool make_geo(long long S, int C, int L, int wg_target, int kmax, BnGeo *g)
+{
+    if (S <= 0 || C <= 0 || L <= 0 || L > 256) return false;
+    const long long P = (long long)C * L;
+    if (P % 4 != 0 || P > (1ll << 30)) return false;
+    const int unit = L / gcd_int(L, 4) * 4;
+    g->S = S; g->C = C; g->L = L; g->P = (int)P;
+    g->W = kBnSlice / unit * unit;
+    g->nslice = (int)((P + g->W - 1) / g->W);
+    if (g->nslice > 65535) return false;
+    long long want = wg_target / g->nslice;
+    if (want < 1) want = 1;
+    long long K = (S + want - 1) / want;
+    if (K < 1) K = 1;
+    if (K > kmax) K = kmax;
+    g->K = (int)K;
+    g->nchunk = (S + K - 1) / K;
+    return g->nchunk <= 0x7fffffffll;
+}
+
+struct Lane {
+    int p0;          // first plane position of the lane
+    bool active;
+    long long s0, s1;
+};
+
+__device__ __forceinline__ Lane lane_of(const BnGeo &g)
+{
+    Lane l;
+    const int off = 4 * threadIdx.x;
+    l.p0 = blockIdx.y * g.W + off;
+    l.active = off < g.W && l.p0 < g.P;
+    l.s0 = (long long)blockIdx.x * g.K;
+    l.s1 = l.s0 + g.K < g.S ? l.s0 + g.K : g.S;
+    return l;
+}
+
+// sum the per-position partials of every channel of this slice and write them to partial[c][chunk]
+__device__ __forceinline__ void channel_reduce(const BnGeo &g, const double (&a)[4], const double (&b)[4],
+                                               double *s_a, double *s_b, double2 *partial)
+{
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        s_a[4 * threadIdx.x + i] = a[i];
+        s_b[4 * threadIdx.x + i] = b[i];
+    }
+    __syncthreads();
+    const int base = blockIdx.y * g.W;
+    const int span = g.P - base < g.W ? g.P - base : g.W;
+    const int nch = span / g.L, c0 = base / g.L;
+    // `tpc` lanes per channel, each sums a strided share of the channel's L positions; a shuffle tree joins them
+    // (tpc is a power of two <= 8, so the lanes of a channel sit in one wave)
+    const int tpc = nch * 8 <= kBnThreads ? 8 : nch * 4 <= kBnThreads ? 4 : nch * 2 <= kBnThreads ? 2 : 1;
+    for (int j0 = 0; j0 < nch; j0 += kBnThreads / tpc) {
+        const int j = j0 + threadIdx.x / tpc, r = threadIdx.x % tpc;
+        double sa = 0.0, sb = 0.0;
+        if (j < nch)
+            for (int i = r; i < g.L; i += tpc) { sa += s_a[j * g.L + i]; sb += s_b[j * g.L + i]; }
+        for (int o = tpc >> 1; o > 0; o >>= 1) { sa += __shfl_xor(sa, o, 64); sb += __shfl_xor(sb, o, 64); }
+        if (j < nch && r == 0) partial[(long long)(c0 + j) * g.nchunk + blockIdx.x] = make_double2(sa, sb);
+    }
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__restrict__ y, BnGeo g,
+                                                              double2 *__restrict__ partial)
+{
+    __shared__ double s_a[kBnSlice], s_b[kBnSlice];
+    const Lane l = lane_of(g);
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (l.active) {
+        const float *src = y + l.s0 * g.P + l.p0;
+#pragma unroll 4
+        for (long long s = l.s0; s < l.s1; ++s, src += g.P) {
+            const float4 v = *reinterpret_cast<const float4 *>(src);
+            const double d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] += d[i]; b[i] = fma(d[i], d[i], b[i]); }
+        }
+    }
+    channel_reduce(g, a, b, s_a, s_b, partial);
+}
+
+__device__ __forceinline__ double2 block_sum2(double2 v, double2 *s_w)
+{
+    v.x = wave_sum_f64(v.x);
+    v.y = wave_sum_f64(v.y);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double2 t = make_double2(0.0, 0.0);
+    for (int w = 0; w < kBnThreads / 64; ++w) { t.x += s_w[w].x; t.y += s_w[w].y; }
+    return t;
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(const double2 *__restrict__ partial, long long nchunk,
+                                                                 long long S, int L, const float *gamma,
+                                                                 const float *beta, float *running_mean,
+                                                                 float *running_var, double momentum, double eps,
+                                                                 float *save_mean, float *save_invstd, float *scale,
+                                                                 float *shift)
+{
+    __shared__ double2 s_w[kBnThreads / 64];
+    const int c = blockIdx.x;
+    double2 acc = make_double2(0.0, 0.0);
+    for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) {
+        const double2 p = partial[c * nchunk + i];
+        acc.x += p.x; acc.y += p.y;
+    }
+    acc = block_sum2(acc, s_w);
+    if (threadIdx.x == 0) {
+        const double n = (double)S * L;
+        const double mean = acc.x / n;
+        double var = acc.y / n - mean * mean;
+        var = var > 0.0 ? var : 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + eps));
+        const float m = (float)mean;
+        const float sc = gamma[c] * invstd;
+        save_mean[c] = m;
+        save_invstd[c] = invstd;
+        scale[c] = sc;
+        shift[c] = fmaf(-m, sc, beta[c]);
+        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        if (running_var) {
+            const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+    }
+}
+
+__device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.0f ? u : u * slope; }
+
+template <bool POOL>
+__global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__restrict__ y, BnGeo g,
+                                                              const float *__restrict__ scale,
+                                                              const float *__restrict__ shift, float slope,
+                                                              float *__restrict__ out)
+{
+    const Lane l = lane_of(g);
+    if (!l.active) return;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (l.p0 + i) / g.L;
+        sc[i] = scale[c]; sh[i] = shift[c];
+    }
+    const float *src = y + l.s0 * g.P + l.p0;
+    const int po = POOL ? g.P / 2 : g.P;
+    float *dst = out + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
+#pragma unroll 4
+    for (long long s = l.s0; s < l.s1; ++s, src += g.P, dst += po) {
+        const float4 v = *reinterpret_cast<const float4 *>(src);
+        const float z0 = lrelu(fmaf(v.x, sc[0], sh[0]), slope), z1 = lrelu(fmaf(v.y, sc[1], sh[1]), slope);
+        const float z2 = lrelu(fmaf(v.z, sc[2], sh[2]), slope), z3 = lrelu(fmaf(v.w, sc[3], sh[3]), slope);
+        if (POOL) *reinterpret_cast<float2 *>(dst) = make_float2(z0 >= z1 ? z0 : z1, z2 >= z3 ? z2 : z3);
+        else *reinterpret_cast<float4 *>(dst) = make_float4(z0, z1, z2, z3);
+    }
+}
+
+struct BwdConst { float sc[4], sh[4], mu[4], is[4]; };
+
+__device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int p0, const float *scale, const float *shift,
+                                              const float *mean, const float *invstd)
+{
+    BwdConst k;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (p0 + i) / g.L;
+        k.sc[i] = scale[c]; k.sh[i] = shift[c]; k.mu[i] = mean[c]; k.is[i] = invstd[c];
+    }
+    return k;
+}
+
+// gradient with respect to the BatchNorm output u, and xhat, for the lane's four positions of one sample
+template <bool POOL>
+__device__ __forceinline__ void grad_u(const float *src, const float *gsrc, const BwdConst &k, float slope,
+                                       float (&du)[4], float (&xh)[4])
+{
+    const float4 v4 = *reinterpret_cast<const float4 *>(src);
+    const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+    float u[4], gz[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        u[i] = fmaf(v[i], k.sc[i], k.sh[i]);
+        xh[i] = (v[i] - k.mu[i]) * k.is[i];
+    }
+    if (POOL) {
+        // the pair's winner takes the gradient; max_pool1d keeps the FIRST maximum on a tie
+        const float2 d = *reinterpret_cast<const float2 *>(gsrc);
+        const bool f0 = lrelu(u[0], slope) >= lrelu(u[1], slope), f1 = lrelu(u[2], slope) >= lrelu(u[3], slope);
+        gz[0] = f0 ? d.x : 0.0f; gz[1] = f0 ? 0.0f : d.x;
+        gz[2] = f1 ? d.y : 0.0f; gz[3] = f1 ? 0.0f : d.y;
+    } else {
+        const float4 d = *reinterpret_cast<const float4 *>(gsrc);
+        gz[0] = d.x; gz[1] = d.y; gz[2] = d.z; gz[3] = d.w;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) du[i] = u[i] > 0.0f ? gz[i] : gz[i] * slope;
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *__restrict__ y,
+                                                                   const float *__restrict__ dz, BnGeo g,
+                                                                   const float *__restrict__ scale,
+                                                                   const float *__restrict__ shift,
+                                                                   const float *__restrict__ mean,
+                                                                   const float *__restrict__ invstd, float slope,
+                                                                   double2 *__restrict__ partial)
+{
+    __shared__ double s_a[kBnSlice], s_b[kBnSlice];
+    const Lane l = lane_of(g);
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (l.active) {
+        const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
+        const int po = POOL ? g.P / 2 : g.P;
+        const float *src = y + l.s0 * g.P + l.p0;
+        const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
+#pragma unroll 4
+        for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po) {
+            float du[4], xh[4];
+            grad_u<POOL>(src, gsrc, k, slope, du, xh);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] += (double)du[i]; b[i] = fma((double)du[i], (double)xh[i], b[i]); }
+        }
+    }
+    channel_reduce(g, a, b, s_a, s_b, partial);
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 *__restrict__ partial,
+                                                                  long long nchunk, long long S, int L,
+                                                                  float *dgamma, float *dbeta, float *k1, float *k2)
+{
+    __shared__ double2 s_w[kBnThreads / 64];
+    const int c = blockIdx.x;
+    double2 acc = make_double2(0.0, 0.0);
+    for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) {
+        const double2 p = partial[c * nchunk + i];
+        acc.x += p.x; acc.y += p.y;
+    }
+    acc = block_sum2(acc, s_w);
+    if (threadIdx.x == 0) {
+        const double n = (double)S * L;
+        dbeta[c] = (float)acc.x;
+        dgamma[c] = (float)acc.y;
+        k1[c] = (float)(acc.x / n);
+        k2[c] = (float)(acc.y / n);
+    }
+}
+
+template <bool POOL>
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *__restrict__ y,
+                                                                  const float *__restrict__ dz, BnGeo g,
+                                                                  const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ invstd,
+                                                                  const float *__restrict__ k1,
+                                                                  const float *__restrict__ k2, float slope,
+                                                                  float *__restrict__ dy)
+{
+    const Lane l = lane_of(g);
+    if (!l.active) return;
+    const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
+    float m1[4], m2[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = (l.p0 + i) / g.L;
+        m1[i] = k1[c]; m2[i] = k2[c];
+    }
+    const int po = POOL ? g.P / 2 : g.P;
+    const float *src = y + l.s0 * g.P + l.p0;
+    const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
+    float *dst = dy + l.s0 * g.P + l.p0;
+#pragma unroll 4
+    for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po, dst += g.P) {
+        float du[4], xh[4], r[4];
+        grad_u<POOL>(src, gsrc, k, slope, du, xh);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) r[i] = k.sc[i] * ((du[i] - m1[i]) - xh[i] * m2[i]);
+        *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+    }
+}
+
+// scale / shift of the forward pass, rebuilt from (gamma, beta, mean, 1/std) with the forward's own operations so
+// that the recomputed u = y * scale + shift has the forward's bits (the pool winner and the activation sign
+// depend on it)
+__global__ void bn_coef_kernel(const float *gamma, const float *beta, const float *mean, const float *invstd, int C,
+                               float *scale, float *shift)
+{
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] * invstd[c];
+    scale[c] = sc;
+    shift[c] = fmaf(-mean[c], sc, beta[c]);
+}
+
+// workspace: double2 partial[C * nchunk_max] | float coef[4 * C]
+constexpr int kStatsWgs = 4096, kStatsK = 64;      // reductions: few partial sums
+constexpr int kStreamWgs = 8192, kStreamK = 16;  // element-wise passes: short loops, many workgroups
+
+size_t partial_bytes(const BnGeo &g) { return (size_t)g.C * (size_t)g.nchunk * sizeof(double2); }
+
+}  // namespace
+
+extern "C" size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L)
+{
+    BnGeo g;
+    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &g)) return 0;
+    return partial_bytes(g) + 4 * (size_t)C * sizeof(float);
+}
+
+extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const float *gamma,
+                                         const float *beta, float *running_mean, float *running_var, double momentum,
+                                         double eps, double negative_slope, int pool, float *out, float *save_mean,
+                                         float *save_invstd, void *workspace, size_t workspace_bytes,
+                                         pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (!y || !gamma || !beta || !out || !save_mean || !save_invstd || !workspace) return POF_E_BADARG;
+    BnGeo gs, ga;
+    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga))
+        return POF_E_SHAPE;
+    if (pool && (L & 1)) return POF_E_SHAPE;
+    if (!(eps >= 0.0)) return POF_E_BADARG;
+    if (workspace_bytes < partial_bytes(gs) + 4 * (size_t)C * sizeof(float)) return POF_E_WORKSPACE;
+    double2 *partial = static_cast<double2 *>(workspace);
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + partial_bytes(gs));
+    float *scale = coef, *shift = coef + C;
+    hipStream_t st = pof_stream(stream);
+    bn_stats_kernel<<<dim3((unsigned)gs.nchunk, gs.nslice), kBnThreads, 0, st>>>(y, gs, partial);
+    POF_CHECK_LAUNCH();
+    bn_finalize_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, gamma, beta, running_mean, running_var,
+                                                 momentum, eps, save_mean, save_invstd, scale, shift);
+    POF_CHECK_LAUNCH();
+    const dim3 grid((unsigned)ga.nchunk, ga.nslice);
+    if (pool) bn_apply_kernel<true><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
+    else bn_apply_kernel<false><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
+extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
+                                          const float *gamma, const float *beta, const float *save_mean,
+                                          const float *save_invstd, double negative_slope, int pool, float *dy,
+                                          float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
+                                          pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (!y || !dz || !gamma || !beta || !save_mean || !save_invstd || !dy || !dgamma || !dbeta || !workspace)
+        return POF_E_BADARG;
+    BnGeo gs, ga;
+    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga))
+        return POF_E_SHAPE;
+    if (pool && (L & 1)) return POF_E_SHAPE;
+    if (workspace_bytes < partial_bytes(gs) + 4 * (size_t)C * sizeof(float)) return POF_E_WORKSPACE;
+    double2 *partial = static_cast<double2 *>(workspace);
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + partial_bytes(gs));
+    float *scale = coef, *shift = coef + C, *k1 = coef + 2 * C, *k2 = coef + 3 * C;
+    const float slope = (float)negative_slope;
+    hipStream_t st = pof_stream(stream);
+    bn_coef_kernel<<<(C + 255) / 256, 256, 0, st>>>(gamma, beta, save_mean, save_invstd, C, scale, shift);
+    POF_CHECK_LAUNCH();
+    const dim3 rgrid((unsigned)gs.nchunk, gs.nslice), dgrid((unsigned)ga.nchunk, ga.nslice);
+    if (pool) bn_bwd_reduce_kernel<true><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, scale, shift, save_mean, save_invstd, slope, partial);
+    else bn_bwd_reduce_kernel<false><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, scale, shift, save_mean, save_invstd, slope, partial);
+    POF_CHECK_LAUNCH();
+    bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, dgamma, dbeta, k1, k2);
+    POF_CHECK_LAUNCH();
+    if (pool) bn_bwd_dgrad_kernel<true><<<dgrid, kBnThreads, 0, st>>>(y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy);
+    else bn_bwd_dgrad_kernel<false><<<dgrid, kBnThreads, 0, st>>>(y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy);
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}

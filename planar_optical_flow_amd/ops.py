@@ -351,6 +351,65 @@ def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None
     return out
 
 
+def bn_lrelu_pool_supported(S, C, L, pool=False):
+    """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, L even when pooled)."""
+    if pool and (L & 1):
+        return False
+    return S > 0 and int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L))) > 0
+
+
+def _bn_workspace(S, C, L, device):
+    nbytes = int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L)))
+    if nbytes == 0:
+        raise ValueError("bn_lrelu_pool: unsupported shape S=%d C=%d L=%d (needs L <= 256 and C*L %% 4 == 0)" % (S, C, L))
+    return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device), nbytes
+
+
+def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
+                          negative_slope=0.1, pool=False):
+    """N2 training tail: y [S,C,L] f32 (convolution output) -> (z [S,C,L or L//2], save_mean [C], save_invstd [C]);
+    z = max_pool1d?(leaky_relu(batch_norm_train(y))).  running_mean / running_var are updated in place."""
+    y = _dev(y, torch.float32, "y")
+    gamma = _dev(gamma, torch.float32, "gamma")
+    beta = _dev(beta, torch.float32, "beta")
+    S, C, L = y.shape
+    if gamma.numel() != C or beta.numel() != C:
+        raise ValueError("gamma / beta must have C entries")
+    for name, t in (("running_mean", running_mean), ("running_var", running_var)):
+        if t is not None and (_dev(t, torch.float32, name).numel() != C):
+            raise ValueError("%s must have C entries" % name)
+    ws, nbytes = _bn_workspace(S, C, L, y.device)
+    out = torch.empty((S, C, L // 2 if pool else L), dtype=torch.float32, device=y.device)
+    mean = torch.empty(C, dtype=torch.float32, device=y.device)
+    invstd = torch.empty(C, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.call("pof_bn_lrelu_pool_forward", _ptr(y), S, C, L, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                  _ptr(running_var), float(momentum), float(eps), float(negative_slope), int(bool(pool)), _ptr(out),
+                  _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream())
+    return out, mean, invstd
+
+
+def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_slope=0.1, pool=False):
+    """Backward of bn_lrelu_pool_forward: -> (dy [S,C,L], dgamma [C], dbeta [C])."""
+    y = _dev(y, torch.float32, "y")
+    dz = _dev(dz, torch.float32, "dz")
+    S, C, L = y.shape
+    if tuple(dz.shape) != (S, C, L // 2 if pool else L):
+        raise ValueError("dz must be [S, C, %s]" % ("L//2" if pool else "L"))
+    for name, t in (("gamma", gamma), ("beta", beta), ("save_mean", save_mean), ("save_invstd", save_invstd)):
+        if _dev(t, torch.float32, name).numel() != C:
+            raise ValueError("%s must have C entries" % name)
+    ws, nbytes = _bn_workspace(S, C, L, y.device)
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        _lib.call("pof_bn_lrelu_pool_backward", _ptr(y), _ptr(dz), S, C, L, _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                  _ptr(save_invstd), float(negative_slope), int(bool(pool)), _ptr(dy), _ptr(dgamma), _ptr(dbeta),
+                  _ptr(ws), nbytes, _stream())
+    return dy, dgamma, dbeta
+
+
 def segment_inputs(points, centers, oris, radius=0.4, input_size=64, min_segment_size=5, seed=0,
                    return_mask=False):
     """N3: points [Np,D] f64, centers [S,D] f64, oris [S] f64 -> (x [S,input_size,D+1] f32, count [S] i32

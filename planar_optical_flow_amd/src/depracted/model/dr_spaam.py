@@ -147,8 +147,8 @@ class DROW(nn.Module):
         """One trunk block; pooled blocks pool after their last layer.  Three routes:
         eval + fuse_for_inference(): the HIP conv kernels (17 ms per B = 32 forward); eval without it on
         the GPU: the channels-last GEMM form below (39 ms; MIOpen's inference path takes 234 ms on these
-        shapes); training and CPU: the plain torch modules (MIOpen's training-mode solvers are fine:
-        40 ms per fwd + bwd at B = 8 against 58 ms for the GEMM form)."""
+        shapes); training on the GPU: MIOpen convolutions + the fused BatchNorm/LeakyReLU/pool tail
+        (_run_block_train); CPU: the plain torch modules."""
         fused = getattr(self, "_fused", None)
         if fused is not None and not self.training and x.is_cuda and not torch.is_grad_enabled():
             x = x.contiguous().float()
@@ -172,8 +172,29 @@ class DROW(nn.Module):
             return out
         if x.is_cuda and not self.training and getattr(self, "gemm_trunk", True):
             return self._run_block_gemm(x, getattr(self, name), pool)
+        if x.is_cuda and self.training and getattr(self, "fused_train_tail", True):
+            return self._run_block_train(x, getattr(self, name), pool)
         out = getattr(self, name)(x)
         return torch.max_pool1d(out, kernel_size=2) if pool else out
+
+    @staticmethod
+    def _run_block_train(x, block, pool):
+        """Training on the GPU: the convolutions stay MIOpen's, the BatchNorm(train) + LeakyReLU [+ max-pool]
+        tail of every unit and its backward pass run as the fused HIP passes of ``pof::bn_lrelu_pool`` (the
+        framework's own kernels for that tail take 17 ms of a 41 ms step on sequences this short)."""
+        out = x
+        for i, unit in enumerate(block):
+            conv, bn, act = unit[0], unit[1], unit[2]
+            last = pool and i == len(block) - 1
+            y = conv(out)
+            if type(bn) is nn.BatchNorm1d and bn.training and bn.affine and y.dtype == torch.float32 \
+                    and ops.bn_lrelu_pool_supported(y.shape[0], y.shape[1], y.shape[2], last):
+                out = torch_ops.bn_lrelu_pool_train(y, bn, act.negative_slope, last)
+            else:   # SyncBatchNorm, frozen statistics, autocast, odd shapes: the modules themselves
+                out = act(bn(y))
+                if last:
+                    out = torch.max_pool1d(out, kernel_size=2)
+        return out
 
     @staticmethod
     def _run_block_gemm(x, block, pool):

@@ -16,6 +16,10 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
         float window_depth, int num_cutout_pts, float padding_val, bool area_mode, bool half_out) -> Tensor
     pof::conv3_bn_lrelu(Tensor x, Tensor wt, Tensor scale, Tensor shift, bool pool, float negative_slope) -> Tensor
     pof::rotate_flow(Tensor flow, Tensor tab, bool to_canonical) -> Tensor
+    pof::bn_lrelu_pool(Tensor y, Tensor gamma, Tensor beta, Tensor(a!)? running_mean, Tensor(b!)? running_var,
+        float momentum, float eps, float negative_slope, bool pool) -> (Tensor z, Tensor mean, Tensor invstd)
+    pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
+        float negative_slope, bool pool) -> (Tensor, Tensor, Tensor)
 """
 from typing import Optional, Tuple
 
@@ -144,6 +148,71 @@ def conv3_bn_lrelu(x: torch.Tensor, wt: torch.Tensor, scale: torch.Tensor, shift
 def _(x, wt, scale, shift, pool, negative_slope):
     S, _, L = x.shape
     return x.new_empty((S, wt.shape[2], L // 2 if pool else L))
+
+
+# ------------------------------------------------------------------------------------------------- N2 (training)
+@torch.library.custom_op("pof::bn_lrelu_pool", mutates_args=("running_mean", "running_var"), device_types="cuda")
+def bn_lrelu_pool(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+                  running_var: Optional[torch.Tensor], momentum: float, eps: float, negative_slope: float,
+                  pool: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    z, mean, invstd = ops.bn_lrelu_pool_forward(y.contiguous(), gamma.contiguous(), beta.contiguous(), running_mean,
+                                                running_var, momentum, eps, negative_slope, pool)
+    return z, mean, invstd
+
+
+@bn_lrelu_pool.register_fake
+def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
+    S, C, L = y.shape
+    return (y.new_empty((S, C, L // 2 if pool else L)), y.new_empty((C,)), y.new_empty((C,)))
+
+
+@torch.library.custom_op("pof::bn_lrelu_pool_backward", mutates_args=(), device_types="cuda")
+def bn_lrelu_pool_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                           mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, pool: bool
+                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    dy, dgamma, dbeta = ops.bn_lrelu_pool_backward(y, dz.contiguous().float(), gamma.contiguous(), beta.contiguous(),
+                                                   mean, invstd, negative_slope, pool)
+    return dy, dgamma, dbeta
+
+
+@bn_lrelu_pool_backward.register_fake
+def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool):
+    return torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+
+
+class BnLreluPool(torch.autograd.Function):
+    """Autograd wrapper of pof::bn_lrelu_pool.  The operator updates the running statistics in place, and the
+    dispatcher only accepts autograd formulas for functional operators -- hence a Function around the two ops
+    (both still visible to torch.compile through their fake kernels)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
+        z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+                                                      negative_slope, pool)
+        ctx.save_for_backward(y, gamma, beta, mean, invstd)
+        ctx.negative_slope, ctx.pool = negative_slope, pool
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        y, gamma, beta, mean, invstd = ctx.saved_tensors
+        dy, dgamma, dbeta = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
+                                                                 ctx.negative_slope, ctx.pool)
+        return dy, dgamma, dbeta, None, None, None, None, None, None
+
+
+def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
+    """Training-mode tail of a trunk unit on the fused kernels: z = max_pool1d?(leaky_relu(bn(y))) for a
+    ``torch.nn.BatchNorm1d`` in training mode, with its running statistics and batch counter updated as the
+    module itself would."""
+    momentum = bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if momentum is None:    # cumulative moving average
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, float(momentum if momentum is not None else 0.0),
+                             float(bn.eps), float(negative_slope), bool(pool))
 
 
 # ------------------------------------------------------------------------------------------------- A4

@@ -96,3 +96,87 @@ def test_torch_compile_traces_through_the_ops():
     scale = max(b.abs().max().item() for b in ge)
     for a, b in zip(gc, ge):                                    # on the global gradient scale (float32 round-off)
         assert (a - b).abs().max().item() <= 2e-3 * scale, ((a - b).abs().max().item(), scale)
+
+
+# ---------------------------------------------------------------------------------- N2 training tail
+def _torch_tail(y, bn, slope, pool):
+    out = torch.nn.functional.leaky_relu(bn(y), slope)
+    return torch.max_pool1d(out, 2) if pool else out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C,L,pool", [(37, 64, 48, False), (37, 128, 48, True), (19, 256, 12, True),
+                                         (23, 128, 6, False), (5, 512, 12, True), (3, 6, 10, True),
+                                         (300, 64, 48, True), (1, 8, 256, False)])
+def test_bn_lrelu_pool_matches_torch_modules(S, C, L, pool):
+    """Forward, running statistics and all three gradients of the fused training tail against
+    BatchNorm1d(train) -> leaky_relu -> max_pool1d of torch itself (float64 copy as the referee)."""
+    from planar_optical_flow_amd import torch_ops
+    g = torch.Generator(device="cuda").manual_seed(S * 1000 + C + L)
+    y = (torch.randn(S, C, L, device="cuda", generator=g) * 1.7 + 0.4).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=g)
+        bn.bias.uniform_(-0.5, 0.5, generator=g)
+        bn.running_mean.uniform_(-1, 1, generator=g)
+        bn.running_var.uniform_(0.5, 2, generator=g)
+    ref_bn = torch.nn.BatchNorm1d(C).cuda().double()
+    ref_bn.load_state_dict(bn.state_dict())
+    y64 = y.detach().double().requires_grad_(True)
+
+    z = torch_ops.bn_lrelu_pool_train(y, bn, 0.1, pool)
+    z64 = _torch_tail(y64, ref_bn, 0.1, pool)
+    assert z.shape == z64.shape
+    assert torch.allclose(z.double(), z64, rtol=1e-5, atol=2e-5)
+    assert torch.allclose(bn.running_mean.double(), ref_bn.running_mean, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref_bn.running_var, rtol=1e-6, atol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+
+    gz = torch.randn(z.shape, device="cuda", generator=g)
+    z.backward(gz)
+    z64.backward(gz.double())
+    scale = float(y64.grad.abs().max())
+    assert float((y.grad.double() - y64.grad).abs().max()) <= 2e-5 * max(scale, 1.0)
+    for got, want in ((bn.weight.grad, ref_bn.weight.grad), (bn.bias.grad, ref_bn.bias.grad)):
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+def test_bn_lrelu_pool_rejects_unsupported_shapes():
+    from planar_optical_flow_amd import ops
+    assert not ops.bn_lrelu_pool_supported(4, 3, 5)            # C*L % 4 != 0
+    assert not ops.bn_lrelu_pool_supported(4, 4, 300)          # L > 256
+    assert not ops.bn_lrelu_pool_supported(4, 4, 7, pool=True)  # odd L cannot be pooled in pairs
+    with pytest.raises(ValueError):
+        ops.bn_lrelu_pool_forward(torch.zeros(4, 3, 5, device="cuda"), torch.ones(3, device="cuda"),
+                                  torch.zeros(3, device="cuda"))
+    with pytest.raises(TypeError):
+        ops.bn_lrelu_pool_forward(torch.zeros(4, 4, 8), torch.ones(4), torch.zeros(4))   # CPU tensors: no fallback
+
+
+@pytest.mark.gpu
+def test_drow_training_step_fused_tail_matches_module_path():
+    """One DROW training step (loss, every parameter gradient, running statistics) with the fused tail against
+    the same step through the plain torch modules."""
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import DROW
+    torch.manual_seed(3)
+    a = DROW(num_scans=2).cuda().train()
+    b = DROW(num_scans=2).cuda().train()
+    b.load_state_dict(a.state_dict())
+    b.fused_train_tail = False
+    x = torch.rand(2, 60, 2, 48, device="cuda") * 3
+    outs = []
+    for m in (a, b):
+        cls, reg = m(x)
+        loss = cls.square().mean() + reg.square().mean()
+        loss.backward()
+        outs.append((cls.detach(), reg.detach(), loss.detach()))
+    assert torch.allclose(outs[0][0], outs[1][0], rtol=1e-3, atol=1e-4)
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-3, atol=1e-4)
+    gscale = max(float(p.grad.abs().max()) for p in b.parameters() if p.grad is not None)
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert (p.grad is None) == (q.grad is None), n
+        if p.grad is not None:
+            assert float((p.grad - q.grad).abs().max()) <= 2e-3 * gscale, n
+    for (n, p), q in zip(a.named_buffers(), b.buffers()):
+        assert torch.allclose(p.double(), q.double(), rtol=1e-4, atol=1e-5), n

@@ -32,9 +32,10 @@ for _ in range(5): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 print("DR-SPAAM forward B=%d [%s]: %.2f ms/step  %.0f scans/s" % (B, mode, dt * 1e3, B / dt), flush=True)
-if mode in ("train", "train-miopen"):
+if mode in ("train", "train-miopen", "train-modules"):
     # one optimisation-style step: forward in training mode (BatchNorm batch statistics) + backward
     m.train()
+    m.fused_train_tail = mode != "train-modules"   # train-modules: the framework's own BatchNorm / LeakyReLU / pool
     x = ops.cutout(scans, tab, **kw)
     def tstep():
         for p in m.parameters(): p.grad = None
@@ -43,7 +44,7 @@ if mode in ("train", "train-miopen"):
     for _ in range(2): tstep()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(3): tstep()
+    for _ in range(5): tstep()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 3
+    dt = (time.perf_counter() - t0) / 5
     print("DR-SPAAM train step (fwd+bwd) B=%d [%s]: %.1f ms  peak mem %.1f GB" % (B, mode, dt * 1e3, torch.cuda.max_memory_allocated() / 1e9), flush=True)
