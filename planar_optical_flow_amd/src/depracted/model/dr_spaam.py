@@ -173,20 +173,25 @@ class DROW(nn.Module):
         if x.is_cuda and not self.training and getattr(self, "gemm_trunk", True):
             return self._run_block_gemm(x, getattr(self, name), pool)
         if x.is_cuda and self.training and getattr(self, "fused_train_tail", True):
-            return self._run_block_train(x, getattr(self, name), pool)
+            return self._run_block_train(x, getattr(self, name), pool, getattr(self, "hip_train_conv", True))
         out = getattr(self, name)(x)
         return torch.max_pool1d(out, kernel_size=2) if pool else out
 
     @staticmethod
-    def _run_block_train(x, block, pool):
-        """Training on the GPU: the convolutions stay MIOpen's, the BatchNorm(train) + LeakyReLU [+ max-pool]
-        tail of every unit and its backward pass run as the fused HIP passes of ``pof::bn_lrelu_pool`` (the
-        framework's own kernels for that tail take 17 ms of a 41 ms step on sequences this short)."""
+    def _run_block_train(x, block, pool, hip_conv=True):
+        """Training on the GPU: convolution forward and data gradient on the HIP implicit-GEMM kernel
+        (``torch_ops.Conv3Train``; the weight gradient stays MIOpen's), the BatchNorm(train) + LeakyReLU
+        [+ max-pool] tail of every unit and its backward pass as the fused HIP passes of ``pof::bn_lrelu_pool``
+        (the framework's own kernels for that tail take 17 ms of a 41 ms step on sequences this short)."""
         out = x
         for i, unit in enumerate(block):
             conv, bn, act = unit[0], unit[1], unit[2]
             last = pool and i == len(block) - 1
-            y = conv(out)
+            if hip_conv and conv.kernel_size == (3,) and conv.padding == (1,) and conv.stride == (1,) \
+                    and conv.dilation == (1,) and conv.groups == 1 and out.dtype == torch.float32:
+                y = torch_ops.conv3_train(out, conv)
+            else:
+                y = conv(out)
             if type(bn) is nn.BatchNorm1d and bn.training and bn.affine and y.dtype == torch.float32 \
                     and ops.bn_lrelu_pool_supported(y.shape[0], y.shape[1], y.shape[2], last):
                 out = torch_ops.bn_lrelu_pool_train(y, bn, act.negative_slope, last)

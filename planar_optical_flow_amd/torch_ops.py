@@ -215,6 +215,44 @@ def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
                              float(bn.eps), float(negative_slope), bool(pool))
 
 
+class Conv3Train(torch.autograd.Function):
+    """Conv1d(kernel_size=3, padding=1) of a trunk unit in training: forward and the data gradient on the
+    float32-MFMA implicit-GEMM kernel of the inference trunk (``pof::conv3_bn_lrelu`` with unit scale, the bias
+    as shift and slope 1 = no activation; the data gradient is the same convolution of dy with the taps
+    reversed and the channel roles swapped).  Both read and write [S][C][L] as it lies -- the library's NHWC
+    kernels transpose every operand first (13 % of a training step).  The weight / bias gradient is a
+    reduction over all S * L columns and stays the library's ``convolution_backward``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        co = weight.shape[0]
+        wt = weight.detach().permute(2, 1, 0).contiguous()
+        shift = bias.detach() if bias is not None else weight.new_zeros(co)
+        y = torch.ops.pof.conv3_bn_lrelu(x, wt, weight.new_ones(co), shift, False, 1.0)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        co, ci, _ = weight.shape
+        gy = gy.contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().flip(2).permute(2, 0, 1).contiguous()          # [3][Co][Ci]
+            dx = torch.ops.pof.conv3_bn_lrelu(gy, wd, weight.new_ones(ci), weight.new_zeros(ci), False, 1.0)
+        _, dw, db = torch.ops.aten.convolution_backward(gy, x, weight, [co], [1], [1], [1], False, [0], 1,
+                                                        [False, ctx.needs_input_grad[1],
+                                                         ctx.has_bias and ctx.needs_input_grad[2]])
+        return dx, dw, db
+
+
+def conv3_train(x, conv):
+    """``conv(x)`` for a ``torch.nn.Conv1d(kernel_size=3, padding=1)`` on the HIP forward / data-gradient kernels."""
+    return Conv3Train.apply(x.contiguous(), conv.weight, conv.bias)
+
+
 # ------------------------------------------------------------------------------------------------- A4
 @torch.library.custom_op("pof::rotate_flow", mutates_args=(), device_types="cuda")
 def rotate_flow(flow: torch.Tensor, tab: torch.Tensor, to_canonical: bool) -> torch.Tensor:

@@ -180,3 +180,25 @@ def test_drow_training_step_fused_tail_matches_module_path():
             assert float((p.grad - q.grad).abs().max()) <= 2e-3 * gscale, n
     for (n, p), q in zip(a.named_buffers(), b.buffers()):
         assert torch.allclose(p.double(), q.double(), rtol=1e-4, atol=1e-5), n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Ci,Co,L", [(50, 1, 64, 48), (33, 64, 128, 48), (21, 256, 512, 12), (17, 512, 256, 6),
+                                        (9, 256, 128, 7)])
+def test_conv3_train_matches_conv1d(S, Ci, Co, L):
+    """Forward, data, weight and bias gradients of the HIP training convolution against torch's Conv1d."""
+    from planar_optical_flow_amd import torch_ops
+    torch.manual_seed(S + Ci)
+    conv = torch.nn.Conv1d(Ci, Co, 3, padding=1).cuda()
+    ref = torch.nn.Conv1d(Ci, Co, 3, padding=1).cuda().double()
+    ref.load_state_dict(conv.state_dict())
+    x = torch.randn(S, Ci, L, device="cuda", requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    y = torch_ops.conv3_train(x, conv)
+    y64 = ref(x64)
+    assert float((y.detach().double() - y64.detach()).abs().max()) <= 2e-5 * max(float(y64.detach().abs().max()), 1.0)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    y64.backward(gy.double())
+    for got, want in ((x.grad, x64.grad), (conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
+        assert float((got.double() - want).abs().max()) <= 5e-5 * max(float(want.abs().max()), 1.0)

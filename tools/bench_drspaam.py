@@ -32,10 +32,11 @@ for _ in range(5): step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
 print("DR-SPAAM forward B=%d [%s]: %.2f ms/step  %.0f scans/s" % (B, mode, dt * 1e3, B / dt), flush=True)
-if mode in ("train", "train-miopen", "train-modules"):
+if mode in ("train", "train-miopen", "train-modules", "train-libconv"):
     # one optimisation-style step: forward in training mode (BatchNorm batch statistics) + backward
     m.train()
     m.fused_train_tail = mode != "train-modules"   # train-modules: the framework's own BatchNorm / LeakyReLU / pool
+    m.hip_train_conv = mode != "train-libconv"       # train-libconv: MIOpen convolutions + the fused tail
     x = ops.cutout(scans, tab, **kw)
     def tstep():
         for p in m.parameters(): p.grad = None
