@@ -372,6 +372,8 @@ int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, cons
  * (unbiased variance); save_mean / save_invstd [C] are what the backward pass needs
  * besides y.  backward: dz [S][C][L or L/2] -> dy [S][C][L], dgamma [C], dbeta [C]; the
  * pool routes a gradient to the first maximum of its pair (torch.max_pool1d).
+ * dbias_in [C] (may be NULL) = sum of dy over (S, L): the gradient of a per-channel bias
+ * added in front of the BatchNorm (the convolution's), from the same pass that writes dy.
  * workspace: pof_bn_lrelu_pool_workspace_bytes(S, C, L) bytes (0 = unsupported shape).
  * ---------------------------------------------------------------------- */
 size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L);
@@ -383,8 +385,8 @@ int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const f
 int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
                                const float *gamma, const float *beta, const float *save_mean,
                                const float *save_invstd, double negative_slope, int pool, float *dy,
-                               float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
-                               pof_stream_t stream);
+                               float *dgamma, float *dbeta, float *dbias_in, void *workspace,
+                               size_t workspace_bytes, pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105

@@ -290,7 +290,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 
     }
 }
 
-template <bool POOL>
+// DSUM: also the per-channel sum of dy (= the gradient of a bias added in front of the BatchNorm, i.e. the
+// convolution's bias; zero in exact arithmetic, the framework reduces dy for it in a pass of its own)
+template <bool POOL, bool DSUM>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *__restrict__ y,
                                                                   const float *__restrict__ dz, BnGeo g,
                                                                   const float *__restrict__ scale,
@@ -299,29 +301,54 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *_
                                                                   const float *__restrict__ invstd,
                                                                   const float *__restrict__ k1,
                                                                   const float *__restrict__ k2, float slope,
-                                                                  float *__restrict__ dy)
+                                                                  float *__restrict__ dy,
+                                                                  double2 *__restrict__ partial)
 {
+    __shared__ double s_a[DSUM ? kBnSlice : 1], s_b[DSUM ? kBnSlice : 1];
     const Lane l = lane_of(g);
-    if (!l.active) return;
-    const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
-    float m1[4], m2[4];
+    double acc[4] = {0, 0, 0, 0};
+    if (l.active) {
+        const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
+        float m1[4], m2[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = (l.p0 + i) / g.L;
-        m1[i] = k1[c]; m2[i] = k2[c];
-    }
-    const int po = POOL ? g.P / 2 : g.P;
-    const float *src = y + l.s0 * g.P + l.p0;
-    const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
-    float *dst = dy + l.s0 * g.P + l.p0;
+        for (int i = 0; i < 4; ++i) {
+            const int c = (l.p0 + i) / g.L;
+            m1[i] = k1[c]; m2[i] = k2[c];
+        }
+        const int po = POOL ? g.P / 2 : g.P;
+        const float *src = y + l.s0 * g.P + l.p0;
+        const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
+        float *dst = dy + l.s0 * g.P + l.p0;
+        float part[4] = {0, 0, 0, 0};            // at most kStreamK terms each
 #pragma unroll 4
-    for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po, dst += g.P) {
-        float du[4], xh[4], r[4];
-        grad_u<POOL>(src, gsrc, k, slope, du, xh);
+        for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po, dst += g.P) {
+            float du[4], xh[4], r[4];
+            grad_u<POOL>(src, gsrc, k, slope, du, xh);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) r[i] = k.sc[i] * ((du[i] - m1[i]) - xh[i] * m2[i]);
-        *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            for (int i = 0; i < 4; ++i) {
+                r[i] = k.sc[i] * ((du[i] - m1[i]) - xh[i] * m2[i]);
+                if (DSUM) part[i] += r[i];
+            }
+            *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = (double)part[i];
     }
+    if (DSUM) {
+        const double zero[4] = {0, 0, 0, 0};
+        channel_reduce(g, acc, zero, s_a, s_b, partial);
+    }
+}
+
+__global__ __launch_bounds__(kBnThreads) void bn_sum_final_kernel(const double2 *__restrict__ partial,
+                                                                  long long nchunk, float *out)
+{
+    __shared__ double2 s_w[kBnThreads / 64];
+    const int c = blockIdx.x;
+    double2 acc = make_double2(0.0, 0.0);
+    for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) acc.x += partial[c * nchunk + i].x;
+    acc = block_sum2(acc, s_w);
+    if (threadIdx.x == 0) out[c] = (float)acc.x;
 }
 
 // scale / shift of the forward pass, rebuilt from (gamma, beta, mean, 1/std) with the forward's own operations so
@@ -343,13 +370,20 @@ constexpr int kStreamWgs = 8192, kStreamK = 16;  // element-wise passes: short l
 
 size_t partial_bytes(const BnGeo &g) { return (size_t)g.C * (size_t)g.nchunk * sizeof(double2); }
 
+// the reductions (gs) and the bias sum of the dgrad pass (ga) use the partial-sum area one after the other
+size_t workspace_need(const BnGeo &gs, const BnGeo &ga)
+{
+    const size_t p = partial_bytes(gs) > partial_bytes(ga) ? partial_bytes(gs) : partial_bytes(ga);
+    return p + 4 * (size_t)gs.C * sizeof(float);
+}
+
 }  // namespace
 
 extern "C" size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L)
 {
-    BnGeo g;
-    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &g)) return 0;
-    return partial_bytes(g) + 4 * (size_t)C * sizeof(float);
+    BnGeo gs, ga;
+    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga)) return 0;
+    return workspace_need(gs, ga);
 }
 
 extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const float *gamma,
@@ -365,9 +399,9 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
         return POF_E_SHAPE;
     if (pool && (L & 1)) return POF_E_SHAPE;
     if (!(eps >= 0.0)) return POF_E_BADARG;
-    if (workspace_bytes < partial_bytes(gs) + 4 * (size_t)C * sizeof(float)) return POF_E_WORKSPACE;
+    if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
-    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + partial_bytes(gs));
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * C;
     float *scale = coef, *shift = coef + C;
     hipStream_t st = pof_stream(stream);
     bn_stats_kernel<<<dim3((unsigned)gs.nchunk, gs.nslice), kBnThreads, 0, st>>>(y, gs, partial);
@@ -385,8 +419,8 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
 extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
                                           const float *gamma, const float *beta, const float *save_mean,
                                           const float *save_invstd, double negative_slope, int pool, float *dy,
-                                          float *dgamma, float *dbeta, void *workspace, size_t workspace_bytes,
-                                          pof_stream_t stream)
+                                          float *dgamma, float *dbeta, float *dbias_in, void *workspace,
+                                          size_t workspace_bytes, pof_stream_t stream)
 {
     POF_CLEAR_STALE_ERROR();
     if (!y || !dz || !gamma || !beta || !save_mean || !save_invstd || !dy || !dgamma || !dbeta || !workspace)
@@ -395,9 +429,9 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga))
         return POF_E_SHAPE;
     if (pool && (L & 1)) return POF_E_SHAPE;
-    if (workspace_bytes < partial_bytes(gs) + 4 * (size_t)C * sizeof(float)) return POF_E_WORKSPACE;
+    if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
-    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + partial_bytes(gs));
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * C;
     float *scale = coef, *shift = coef + C, *k1 = coef + 2 * C, *k2 = coef + 3 * C;
     const float slope = (float)negative_slope;
     hipStream_t st = pof_stream(stream);
@@ -409,8 +443,15 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     POF_CHECK_LAUNCH();
     bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, dgamma, dbeta, k1, k2);
     POF_CHECK_LAUNCH();
-    if (pool) bn_bwd_dgrad_kernel<true><<<dgrid, kBnThreads, 0, st>>>(y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy);
-    else bn_bwd_dgrad_kernel<false><<<dgrid, kBnThreads, 0, st>>>(y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy);
+#define POF_DGRAD(P_, D_) bn_bwd_dgrad_kernel<P_, D_><<<dgrid, kBnThreads, 0, st>>>( \
+        y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy, partial)
+    if (dbias_in) { if (pool) POF_DGRAD(true, true); else POF_DGRAD(false, true); }
+    else { if (pool) POF_DGRAD(true, false); else POF_DGRAD(false, false); }
+#undef POF_DGRAD
     POF_CHECK_LAUNCH();
+    if (dbias_in) {
+        bn_sum_final_kernel<<<C, kBnThreads, 0, st>>>(partial, ga.nchunk, dbias_in);
+        POF_CHECK_LAUNCH();
+    }
     return POF_OK;
 }

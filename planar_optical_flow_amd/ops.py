@@ -389,8 +389,10 @@ def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, m
     return out, mean, invstd
 
 
-def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_slope=0.1, pool=False):
-    """Backward of bn_lrelu_pool_forward: -> (dy [S,C,L], dgamma [C], dbeta [C])."""
+def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_slope=0.1, pool=False,
+                           bias_grad=False):
+    """Backward of bn_lrelu_pool_forward: -> (dy [S,C,L], dgamma [C], dbeta [C]) and, with ``bias_grad``, also
+    sum(dy) over (S, L) [C] -- the gradient of the convolution bias in front of the BatchNorm."""
     y = _dev(y, torch.float32, "y")
     dz = _dev(dz, torch.float32, "dz")
     S, C, L = y.shape
@@ -403,11 +405,12 @@ def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_
     dy = torch.empty_like(y)
     dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbias = torch.empty(C, dtype=torch.float32, device=y.device) if bias_grad else None
     with torch.cuda.device(y.device):
         _lib.call("pof_bn_lrelu_pool_backward", _ptr(y), _ptr(dz), S, C, L, _ptr(gamma), _ptr(beta), _ptr(save_mean),
                   _ptr(save_invstd), float(negative_slope), int(bool(pool)), _ptr(dy), _ptr(dgamma), _ptr(dbeta),
-                  _ptr(ws), nbytes, _stream())
-    return dy, dgamma, dbeta
+                  _ptr(dbias), _ptr(ws), nbytes, _stream())
+    return (dy, dgamma, dbeta, dbias) if bias_grad else (dy, dgamma, dbeta)
 
 
 def segment_inputs(points, centers, oris, radius=0.4, input_size=64, min_segment_size=5, seed=0,

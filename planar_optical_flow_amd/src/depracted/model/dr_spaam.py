@@ -187,13 +187,16 @@ class DROW(nn.Module):
         for i, unit in enumerate(block):
             conv, bn, act = unit[0], unit[1], unit[2]
             last = pool and i == len(block) - 1
-            if hip_conv and conv.kernel_size == (3,) and conv.padding == (1,) and conv.stride == (1,) \
-                    and conv.dilation == (1,) and conv.groups == 1 and out.dtype == torch.float32:
-                y = torch_ops.conv3_train(out, conv)
-            else:
-                y = conv(out)
-            if type(bn) is nn.BatchNorm1d and bn.training and bn.affine and y.dtype == torch.float32 \
-                    and ops.bn_lrelu_pool_supported(y.shape[0], y.shape[1], y.shape[2], last):
+            conv_ok = hip_conv and conv.kernel_size == (3,) and conv.padding == (1,) and conv.stride == (1,) \
+                and conv.dilation == (1,) and conv.groups == 1 and conv.padding_mode == "zeros" \
+                and out.dtype == torch.float32
+            tail_ok = type(bn) is nn.BatchNorm1d and bn.training and bn.affine and out.dtype == torch.float32 \
+                and ops.bn_lrelu_pool_supported(out.shape[0], conv.out_channels, out.shape[2], last)
+            if conv_ok and tail_ok:
+                out = torch_ops.trunk_unit_train(out, conv, bn, act.negative_slope, last)
+                continue
+            y = torch_ops.conv3_train(out, conv) if conv_ok else conv(out)
+            if tail_ok and y.dtype == torch.float32:
                 out = torch_ops.bn_lrelu_pool_train(y, bn, act.negative_slope, last)
             else:   # SyncBatchNorm, frozen statistics, autocast, odd shapes: the modules themselves
                 out = act(bn(y))

@@ -19,7 +19,7 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
     pof::bn_lrelu_pool(Tensor y, Tensor gamma, Tensor beta, Tensor(a!)? running_mean, Tensor(b!)? running_var,
         float momentum, float eps, float negative_slope, bool pool) -> (Tensor z, Tensor mean, Tensor invstd)
     pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
-        float negative_slope, bool pool) -> (Tensor, Tensor, Tensor)
+        float negative_slope, bool pool, bool bias_grad) -> (Tensor, Tensor, Tensor, Tensor)
 """
 from typing import Optional, Tuple
 
@@ -168,16 +168,19 @@ def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, 
 
 @torch.library.custom_op("pof::bn_lrelu_pool_backward", mutates_args=(), device_types="cuda")
 def bn_lrelu_pool_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
-                           mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, pool: bool
-                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    dy, dgamma, dbeta = ops.bn_lrelu_pool_backward(y, dz.contiguous().float(), gamma.contiguous(), beta.contiguous(),
-                                                   mean, invstd, negative_slope, pool)
-    return dy, dgamma, dbeta
+                           mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, pool: bool,
+                           bias_grad: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    res = ops.bn_lrelu_pool_backward(y, dz.contiguous().float(), gamma.contiguous(), beta.contiguous(), mean, invstd,
+                                     negative_slope, pool, bias_grad=bias_grad)
+    if bias_grad:
+        return res
+    return res[0], res[1], res[2], gamma.new_empty((0,))
 
 
 @bn_lrelu_pool_backward.register_fake
-def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool):
-    return torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta)
+def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool, bias_grad):
+    return (torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta),
+            gamma.new_empty((gamma.shape[0] if bias_grad else 0,)))
 
 
 class BnLreluPool(torch.autograd.Function):
@@ -196,23 +199,29 @@ class BnLreluPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_z):
         y, gamma, beta, mean, invstd = ctx.saved_tensors
-        dy, dgamma, dbeta = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
-                                                                 ctx.negative_slope, ctx.pool)
+        dy, dgamma, dbeta, _ = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
+                                                                    ctx.negative_slope, ctx.pool, False)
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
-def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
-    """Training-mode tail of a trunk unit on the fused kernels: z = max_pool1d?(leaky_relu(bn(y))) for a
-    ``torch.nn.BatchNorm1d`` in training mode, with its running statistics and batch counter updated as the
-    module itself would."""
+def _bn_train_args(bn):
+    """(running_mean, running_var, momentum, eps) of a BatchNorm in training mode, batch counter advanced as the
+    module itself does."""
     momentum = bn.momentum
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
         if momentum is None:    # cumulative moving average
             momentum = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, float(momentum if momentum is not None else 0.0),
-                             float(bn.eps), float(negative_slope), bool(pool))
+    return rm, rv, float(momentum if momentum is not None else 0.0), float(bn.eps)
+
+
+def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
+    """Training-mode tail of a trunk unit on the fused kernels: z = max_pool1d?(leaky_relu(bn(y))) for a
+    ``torch.nn.BatchNorm1d`` in training mode, with its running statistics and batch counter updated as the
+    module itself would."""
+    rm, rv, momentum, eps = _bn_train_args(bn)
+    return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, momentum, eps, float(negative_slope), bool(pool))
 
 
 class Conv3Train(torch.autograd.Function):
@@ -251,6 +260,50 @@ class Conv3Train(torch.autograd.Function):
 def conv3_train(x, conv):
     """``conv(x)`` for a ``torch.nn.Conv1d(kernel_size=3, padding=1)`` on the HIP forward / data-gradient kernels."""
     return Conv3Train.apply(x.contiguous(), conv.weight, conv.bias)
+
+
+class TrunkUnitTrain(torch.autograd.Function):
+    """One whole trunk unit in training -- Conv1d(3, pad 1) -> BatchNorm1d(train) -> LeakyReLU [-> max_pool1d(2)] --
+    as one autograd node: Conv3Train's kernels for the convolution and its data gradient, pof::bn_lrelu_pool for
+    the tail.  Being one node lets the tail's dgrad pass hand the convolution its bias gradient (the sum of dy it
+    is writing anyway) instead of a reduction pass of its own; only the input x and the convolution output y are
+    kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
+        co = weight.shape[0]
+        wt = weight.detach().permute(2, 1, 0).contiguous()
+        shift = bias.detach() if bias is not None else weight.new_zeros(co)
+        y = torch.ops.pof.conv3_bn_lrelu(x, wt, weight.new_ones(co), shift, False, 1.0)
+        z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+                                                      negative_slope, pool)
+        ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd)
+        ctx.has_bias, ctx.negative_slope, ctx.pool = bias is not None, negative_slope, pool
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        x, weight, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        co, ci, _ = weight.shape
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
+                                                                     ctx.negative_slope, ctx.pool, want_db)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = weight.detach().flip(2).permute(2, 0, 1).contiguous()
+            dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, weight.new_ones(ci), weight.new_zeros(ci), False, 1.0)
+        dw = None
+        if ctx.needs_input_grad[1]:
+            _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
+                                                           [False, True, False])
+        return dx, dw, (db if want_db else None), dgamma, dbeta, None, None, None, None, None, None
+
+
+def trunk_unit_train(x, conv, bn, negative_slope=0.1, pool=False):
+    """``max_pool1d?(leaky_relu(bn(conv(x))))`` for a trunk unit's modules in training mode (see TrunkUnitTrain)."""
+    rm, rv, momentum, eps = _bn_train_args(bn)
+    return TrunkUnitTrain.apply(x.contiguous(), conv.weight, conv.bias, bn.weight, bn.bias, rm, rv, momentum, eps,
+                                float(negative_slope), bool(pool))
 
 
 # ------------------------------------------------------------------------------------------------- A4

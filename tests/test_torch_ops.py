@@ -202,3 +202,36 @@ def test_conv3_train_matches_conv1d(S, Ci, Co, L):
     y64.backward(gy.double())
     for got, want in ((x.grad, x64.grad), (conv.weight.grad, ref.weight.grad), (conv.bias.grad, ref.bias.grad)):
         assert float((got.double() - want).abs().max()) <= 5e-5 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Ci,Co,L,pool", [(40, 1, 64, 48, False), (33, 64, 128, 48, True), (21, 256, 512, 12, True),
+                                             (17, 512, 256, 6, False)])
+def test_trunk_unit_train_matches_modules(S, Ci, Co, L, pool):
+    """The one-node training unit (HIP conv + fused tail + bias gradient from the dgrad pass) against
+    Conv1d -> BatchNorm1d(train) -> LeakyReLU -> max_pool1d in float64."""
+    from planar_optical_flow_amd import torch_ops
+    torch.manual_seed(S + Co)
+    conv, bn = torch.nn.Conv1d(Ci, Co, 3, padding=1).cuda(), torch.nn.BatchNorm1d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    rconv, rbn = torch.nn.Conv1d(Ci, Co, 3, padding=1).cuda().double(), torch.nn.BatchNorm1d(Co).cuda().double()
+    rconv.load_state_dict(conv.state_dict())
+    rbn.load_state_dict(bn.state_dict())
+    x = torch.randn(S, Ci, L, device="cuda", requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    z = torch_ops.trunk_unit_train(x, conv, bn, 0.1, pool)
+    z64 = _torch_tail(rconv(x64), rbn, 0.1, pool)
+    assert torch.allclose(z.detach().double(), z64.detach(), rtol=1e-4, atol=1e-4)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    z64.backward(gz.double())
+    wscale = float(rconv.weight.grad.abs().max())
+    for got, want, scale in ((x.grad, x64.grad, float(x64.grad.abs().max())),
+                             (conv.weight.grad, rconv.weight.grad, wscale),
+                             (conv.bias.grad, rconv.bias.grad, wscale),     # zero up to rounding in both
+                             (bn.weight.grad, rbn.weight.grad, float(rbn.weight.grad.abs().max())),
+                             (bn.bias.grad, rbn.bias.grad, float(rbn.bias.grad.abs().max()))):
+        assert float((got.double() - want).abs().max()) <= 1e-4 * max(scale, 1.0)
+    assert torch.allclose(bn.running_var.double(), rbn.running_var, rtol=1e-5, atol=1e-6)
