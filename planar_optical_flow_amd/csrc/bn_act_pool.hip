@@ -202,14 +202,19 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__res
 
 struct BwdConst { float sc[4], sh[4], mu[4], is[4]; };
 
-__device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int p0, const float *scale, const float *shift,
+// scale / shift are rebuilt from (gamma, beta, mean, 1/std) with the forward's own operations (bn_finalize_kernel),
+// so that the recomputed u = y * scale + shift has the forward's bits: the pool winner and the activation sign
+// depend on it
+__device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int p0, const float *gamma, const float *beta,
                                               const float *mean, const float *invstd)
 {
     BwdConst k;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (p0 + i) / g.L;
-        k.sc[i] = scale[c]; k.sh[i] = shift[c]; k.mu[i] = mean[c]; k.is[i] = invstd[c];
+        k.mu[i] = mean[c]; k.is[i] = invstd[c];
+        k.sc[i] = gamma[c] * k.is[i];
+        k.sh[i] = fmaf(-k.mu[i], k.sc[i], beta[c]);
     }
     return k;
 }
@@ -244,8 +249,8 @@ __device__ __forceinline__ void grad_u(const float *src, const float *gsrc, cons
 template <bool POOL>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *__restrict__ y,
                                                                    const float *__restrict__ dz, BnGeo g,
-                                                                   const float *__restrict__ scale,
-                                                                   const float *__restrict__ shift,
+                                                                   const float *__restrict__ gamma,
+                                                                   const float *__restrict__ beta,
                                                                    const float *__restrict__ mean,
                                                                    const float *__restrict__ invstd, float slope,
                                                                    double2 *__restrict__ partial)
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *
     const Lane l = lane_of(g);
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (l.active) {
-        const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
+        const BwdConst k = bwd_const(g, l.p0, gamma, beta, mean, invstd);
         const int po = POOL ? g.P / 2 : g.P;
         const float *src = y + l.s0 * g.P + l.p0;
         const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
@@ -295,8 +300,8 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 
 template <bool POOL, bool DSUM>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *__restrict__ y,
                                                                   const float *__restrict__ dz, BnGeo g,
-                                                                  const float *__restrict__ scale,
-                                                                  const float *__restrict__ shift,
+                                                                  const float *__restrict__ gamma,
+                                                                  const float *__restrict__ beta,
                                                                   const float *__restrict__ mean,
                                                                   const float *__restrict__ invstd,
                                                                   const float *__restrict__ k1,
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *_
     const Lane l = lane_of(g);
     double acc[4] = {0, 0, 0, 0};
     if (l.active) {
-        const BwdConst k = bwd_const(g, l.p0, scale, shift, mean, invstd);
+        const BwdConst k = bwd_const(g, l.p0, gamma, beta, mean, invstd);
         float m1[4], m2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -349,19 +354,6 @@ __global__ __launch_bounds__(kBnThreads) void bn_sum_final_kernel(const double2 
     for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) acc.x += partial[c * nchunk + i].x;
     acc = block_sum2(acc, s_w);
     if (threadIdx.x == 0) out[c] = (float)acc.x;
-}
-
-// scale / shift of the forward pass, rebuilt from (gamma, beta, mean, 1/std) with the forward's own operations so
-// that the recomputed u = y * scale + shift has the forward's bits (the pool winner and the activation sign
-// depend on it)
-__global__ void bn_coef_kernel(const float *gamma, const float *beta, const float *mean, const float *invstd, int C,
-                               float *scale, float *shift)
-{
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const float sc = gamma[c] * invstd[c];
-    scale[c] = sc;
-    shift[c] = fmaf(-mean[c], sc, beta[c]);
 }
 
 // workspace: double2 partial[C * nchunk_max] | float coef[4 * C]
@@ -432,19 +424,17 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
     float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * C;
-    float *scale = coef, *shift = coef + C, *k1 = coef + 2 * C, *k2 = coef + 3 * C;
+    float *k1 = coef + 2 * C, *k2 = coef + 3 * C;
     const float slope = (float)negative_slope;
     hipStream_t st = pof_stream(stream);
-    bn_coef_kernel<<<(C + 255) / 256, 256, 0, st>>>(gamma, beta, save_mean, save_invstd, C, scale, shift);
-    POF_CHECK_LAUNCH();
     const dim3 rgrid((unsigned)gs.nchunk, gs.nslice), dgrid((unsigned)ga.nchunk, ga.nslice);
-    if (pool) bn_bwd_reduce_kernel<true><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, scale, shift, save_mean, save_invstd, slope, partial);
-    else bn_bwd_reduce_kernel<false><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, scale, shift, save_mean, save_invstd, slope, partial);
+    if (pool) bn_bwd_reduce_kernel<true><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
+    else bn_bwd_reduce_kernel<false><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
     POF_CHECK_LAUNCH();
     bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, dgamma, dbeta, k1, k2);
     POF_CHECK_LAUNCH();
 #define POF_DGRAD(P_, D_) bn_bwd_dgrad_kernel<P_, D_><<<dgrid, kBnThreads, 0, st>>>( \
-        y, dz, ga, scale, shift, save_mean, save_invstd, k1, k2, slope, dy, partial)
+        y, dz, ga, gamma, beta, save_mean, save_invstd, k1, k2, slope, dy, partial)
     if (dbias_in) { if (pool) POF_DGRAD(true, true); else POF_DGRAD(false, true); }
     else { if (pool) POF_DGRAD(true, false); else POF_DGRAD(false, false); }
 #undef POF_DGRAD

@@ -283,11 +283,12 @@ class SpatialDROW(DROW):
             pred_cls, pred_reg = self._forward_fused_cutout(out_template)
             return pred_cls, pred_reg, out_template, feat_fused
         n_scan = x.shape[2]
-        out_template = self._scan_features(x, 0)
-        for i in range(1, n_scan - 1):
-            out_template, _ = self.gate(self._scan_features(x, i), out_template)
-        out_template, feat_fused = self.gate(self._scan_features(x, n_scan - 1), out_template)
-        pred_cls, pred_reg = self._forward_fused_cutout(out_template)
+        with torch_ops.weight_layout_scope():   # the same trunk weights serve every scan of the window
+            out_template = self._scan_features(x, 0)
+            for i in range(1, n_scan - 1):
+                out_template, _ = self.gate(self._scan_features(x, i), out_template)
+            out_template, feat_fused = self.gate(self._scan_features(x, n_scan - 1), out_template)
+            pred_cls, pred_reg = self._forward_fused_cutout(out_template)
         return pred_cls, pred_reg, feat_fused
 
 

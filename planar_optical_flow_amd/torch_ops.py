@@ -224,6 +224,53 @@ def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
     return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, momentum, eps, float(negative_slope), bool(pool))
 
 
+_CONSTS = {}
+
+
+def _const(n, value, like):
+    """A cached [n] float32 vector of ones / zeros on ``like``'s device (unit scale, zero shift of the plain
+    convolution) -- not a fill kernel per call."""
+    key = (like.device, int(n), float(value))
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.full((int(n),), float(value), dtype=torch.float32, device=like.device)
+    return t
+
+
+_LAYOUT_SCOPE = None
+
+
+class weight_layout_scope:
+    """Within this scope (one forward pass of a model) the kernel layouts of a convolution weight are built once
+    per weight instead of once per call -- the first two trunk blocks run once per scan of the window with the
+    same weights.  The cache dies with the scope, so it can never outlive a parameter update."""
+
+    def __enter__(self):
+        global _LAYOUT_SCOPE
+        self._outer = _LAYOUT_SCOPE
+        if _LAYOUT_SCOPE is None:
+            _LAYOUT_SCOPE = {}
+        return self
+
+    def __exit__(self, *exc):
+        global _LAYOUT_SCOPE
+        _LAYOUT_SCOPE = self._outer
+        return False
+
+
+def _weight_layouts(weight, need_dgrad):
+    """([3][Ci][Co] forward layout, [3][Co][Ci] tap-reversed layout of the data gradient or None)."""
+    scope = None if torch.compiler.is_compiling() else _LAYOUT_SCOPE
+    entry = scope.get(id(weight)) if scope is not None else None
+    if entry is None:
+        entry = [weight.detach().permute(2, 1, 0).contiguous(), None, weight]   # keeps `weight` alive: id stays unique
+        if scope is not None:
+            scope[id(weight)] = entry
+    if need_dgrad and entry[1] is None:
+        entry[1] = weight.detach().flip(2).permute(2, 0, 1).contiguous()
+    return entry[0], entry[1]
+
+
 class Conv3Train(torch.autograd.Function):
     """Conv1d(kernel_size=3, padding=1) of a trunk unit in training: forward and the data gradient on the
     float32-MFMA implicit-GEMM kernel of the inference trunk (``pof::conv3_bn_lrelu`` with unit scale, the bias
@@ -235,22 +282,21 @@ class Conv3Train(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         co = weight.shape[0]
-        wt = weight.detach().permute(2, 1, 0).contiguous()
-        shift = bias.detach() if bias is not None else weight.new_zeros(co)
-        y = torch.ops.pof.conv3_bn_lrelu(x, wt, weight.new_ones(co), shift, False, 1.0)
-        ctx.save_for_backward(x, weight)
+        wt, wd = _weight_layouts(weight, ctx.needs_input_grad[0])
+        shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
+        y = torch.ops.pof.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
+        ctx.save_for_backward(x, weight, wd)
         ctx.has_bias = bias is not None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        x, weight, wd = ctx.saved_tensors                                       # wd [3][Co][Ci]
         co, ci, _ = weight.shape
         gy = gy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = weight.detach().flip(2).permute(2, 0, 1).contiguous()          # [3][Co][Ci]
-            dx = torch.ops.pof.conv3_bn_lrelu(gy, wd, weight.new_ones(ci), weight.new_zeros(ci), False, 1.0)
+            dx = torch.ops.pof.conv3_bn_lrelu(gy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         _, dw, db = torch.ops.aten.convolution_backward(gy, x, weight, [co], [1], [1], [1], False, [0], 1,
                                                         [False, ctx.needs_input_grad[1],
                                                          ctx.has_bias and ctx.needs_input_grad[2]])
@@ -272,26 +318,25 @@ class TrunkUnitTrain(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
         co = weight.shape[0]
-        wt = weight.detach().permute(2, 1, 0).contiguous()
-        shift = bias.detach() if bias is not None else weight.new_zeros(co)
-        y = torch.ops.pof.conv3_bn_lrelu(x, wt, weight.new_ones(co), shift, False, 1.0)
+        wt, wd = _weight_layouts(weight, ctx.needs_input_grad[0])
+        shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
+        y = torch.ops.pof.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
         z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
                                                       negative_slope, pool)
-        ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd)
+        ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd, wd)
         ctx.has_bias, ctx.negative_slope, ctx.pool = bias is not None, negative_slope, pool
         return z
 
     @staticmethod
     def backward(ctx, g_z):
-        x, weight, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, weight, y, gamma, beta, mean, invstd, wd = ctx.saved_tensors
         co, ci, _ = weight.shape
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
                                                                      ctx.negative_slope, ctx.pool, want_db)
         dx = None
         if ctx.needs_input_grad[0]:
-            wd = weight.detach().flip(2).permute(2, 0, 1).contiguous()
-            dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, weight.new_ones(ci), weight.new_zeros(ci), False, 1.0)
+            dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         dw = None
         if ctx.needs_input_grad[1]:
             _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
