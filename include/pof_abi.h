@@ -389,6 +389,20 @@ int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int
                                size_t workspace_bytes, pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N2 trunk convolution, weight gradient         src/depracted/model/dr_spaam.py:8-19
+ * dw[co][ci][t] = sum_{s,l} dy[s][co][l] * x[s][ci][l + t - 1]  (Conv1d k = 3, pad = 1):
+ * x [S][Ci][L], dy [S][Co][L] float32 -> dw [Co][Ci][3] float32 (torch's weight layout).
+ * Split-K float32-MFMA GEMM over (sequence, position), deterministic (partial tiles in
+ * the workspace, one reduction pass).  The forward and the data gradient of the same
+ * convolution are pof_conv3_bn_lrelu with unit scale / slope 1 (data gradient: dy as
+ * input, taps reversed, channel roles swapped).
+ * workspace: pof_conv3_wgrad_workspace_bytes(S, Ci, Co, L) bytes (0 = unsupported: L > ~90).
+ * ---------------------------------------------------------------------- */
+size_t pof_conv3_wgrad_workspace_bytes(int S, int Ci, int Co, int L);
+int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, float *dw,
+                    void *workspace, size_t workspace_bytes, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105
  *                                                src/data_handle/jrdb_handle.py:178-256
  * points [Np][D] float64 (D = 2 or 3), centers [S][D], oris [S] -> per detection the

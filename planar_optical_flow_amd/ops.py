@@ -351,6 +351,28 @@ def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None
     return out
 
 
+def conv3_wgrad_supported(S, Ci, Co, L):
+    return S > 0 and int(_lib.load().pof_conv3_wgrad_workspace_bytes(int(S), int(Ci), int(Co), int(L))) > 0
+
+
+def conv3_wgrad(x, dy):
+    """N2 training: weight gradient of Conv1d(k=3, pad=1): x [S,Ci,L] f32, dy [S,Co,L] f32 -> dw [Co,Ci,3] f32."""
+    x = _dev(x, torch.float32, "x")
+    dy = _dev(dy, torch.float32, "dy")
+    S, Ci, L = x.shape
+    if dy.dim() != 3 or dy.shape[0] != S or dy.shape[2] != L:
+        raise ValueError("dy must be [S, Co, L]")
+    Co = dy.shape[1]
+    nbytes = int(_lib.load().pof_conv3_wgrad_workspace_bytes(S, Ci, Co, L))
+    if nbytes == 0:
+        raise ValueError("conv3_wgrad: unsupported shape S=%d Ci=%d Co=%d L=%d" % (S, Ci, Co, L))
+    ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((Co, Ci, 3), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.call("pof_conv3_wgrad", _ptr(x), _ptr(dy), S, Ci, Co, L, _ptr(dw), _ptr(ws), nbytes, _stream())
+    return dw
+
+
 def bn_lrelu_pool_supported(S, C, L, pool=False):
     """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, L even when pooled)."""
     if pool and (L & 1):

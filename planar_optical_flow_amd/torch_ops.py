@@ -18,6 +18,7 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
     pof::rotate_flow(Tensor flow, Tensor tab, bool to_canonical) -> Tensor
     pof::bn_lrelu_pool(Tensor y, Tensor gamma, Tensor beta, Tensor(a!)? running_mean, Tensor(b!)? running_var,
         float momentum, float eps, float negative_slope, bool pool) -> (Tensor z, Tensor mean, Tensor invstd)
+    pof::conv3_wgrad(Tensor x, Tensor dy) -> Tensor
     pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
         float negative_slope, bool pool, bool bias_grad) -> (Tensor, Tensor, Tensor, Tensor)
 """
@@ -224,6 +225,24 @@ def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
     return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, momentum, eps, float(negative_slope), bool(pool))
 
 
+@torch.library.custom_op("pof::conv3_wgrad", mutates_args=(), device_types="cuda")
+def conv3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    return ops.conv3_wgrad(x.contiguous(), dy.contiguous())
+
+
+@conv3_wgrad.register_fake
+def _(x, dy):
+    return x.new_empty((dy.shape[1], x.shape[1], 3))
+
+
+def _weight_grad(x, dy, weight):
+    """dL/dweight of the k = 3 convolution: the split-K MFMA kernel, or the library's for shapes it does not take."""
+    if ops.conv3_wgrad_supported(x.shape[0], x.shape[1], dy.shape[1], x.shape[2]):
+        return torch.ops.pof.conv3_wgrad(x, dy)
+    return torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
+                                               [False, True, False])[1]
+
+
 _CONSTS = {}
 
 
@@ -276,8 +295,8 @@ class Conv3Train(torch.autograd.Function):
     float32-MFMA implicit-GEMM kernel of the inference trunk (``pof::conv3_bn_lrelu`` with unit scale, the bias
     as shift and slope 1 = no activation; the data gradient is the same convolution of dy with the taps
     reversed and the channel roles swapped).  Both read and write [S][C][L] as it lies -- the library's NHWC
-    kernels transpose every operand first (13 % of a training step).  The weight / bias gradient is a
-    reduction over all S * L columns and stays the library's ``convolution_backward``."""
+    kernels transpose every operand first (13 % of a training step).  The weight gradient is the split-K MFMA
+    kernel ``pof::conv3_wgrad``."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
@@ -297,9 +316,8 @@ class Conv3Train(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.ops.pof.conv3_bn_lrelu(gy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
-        _, dw, db = torch.ops.aten.convolution_backward(gy, x, weight, [co], [1], [1], [1], False, [0], 1,
-                                                        [False, ctx.needs_input_grad[1],
-                                                         ctx.has_bias and ctx.needs_input_grad[2]])
+        dw = _weight_grad(x, gy, weight) if ctx.needs_input_grad[1] else None
+        db = gy.sum(dim=(0, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
 
 
@@ -339,8 +357,7 @@ class TrunkUnitTrain(torch.autograd.Function):
             dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         dw = None
         if ctx.needs_input_grad[1]:
-            _, dw, _ = torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
-                                                           [False, True, False])
+            dw = _weight_grad(x, dy, weight)
         return dx, dw, (db if want_db else None), dgamma, dbeta, None, None, None, None, None, None
 
 

@@ -235,3 +235,37 @@ def test_trunk_unit_train_matches_modules(S, Ci, Co, L, pool):
                              (bn.bias.grad, rbn.bias.grad, float(rbn.bias.grad.abs().max()))):
         assert float((got.double() - want).abs().max()) <= 1e-4 * max(scale, 1.0)
     assert torch.allclose(bn.running_var.double(), rbn.running_var, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Ci,Co,L", [(50, 1, 64, 56), (33, 64, 64, 48), (29, 64, 128, 56), (21, 128, 256, 28),
+                                        (40, 256, 512, 14), (37, 512, 256, 7), (19, 256, 128, 6), (11, 3, 5, 9),
+                                        (70, 96, 160, 12), (300, 128, 128, 24), (1, 64, 64, 56)])
+def test_conv3_wgrad_matches_autograd(S, Ci, Co, L):
+    """Split-K MFMA weight gradient against torch's float64 convolution weight gradient (ragged channel counts,
+    odd lengths, sequence counts that do not fill the last stage / split)."""
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S * 7 + Ci + Co + L)
+    x = torch.randn(S, Ci, L, device="cuda", generator=g)
+    dy = torch.randn(S, Co, L, device="cuda", generator=g)
+    w = torch.zeros(Co, Ci, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv1d(x.double(), w, padding=1).backward(dy.double())
+    dw = ops.conv3_wgrad(x, dy)
+    assert dw.shape == (Co, Ci, 3)
+    scale = float(w.grad.abs().max())
+    assert float((dw.double() - w.grad).abs().max()) <= 2e-5 * max(scale, 1.0)
+
+
+@pytest.mark.gpu
+def test_conv3_wgrad_exact_on_integer_data_and_deterministic():
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randint(-3, 4, (200, 64, 28), device="cuda", generator=g).float()
+    dy = torch.randint(-3, 4, (200, 128, 28), device="cuda", generator=g).float()
+    w = torch.zeros(128, 64, 3, device="cuda", dtype=torch.float64, requires_grad=True)
+    torch.nn.functional.conv1d(x.double(), w, padding=1).backward(dy.double())
+    dw = ops.conv3_wgrad(x, dy)
+    assert torch.equal(dw.double(), w.grad)            # sums of small integers: exact in float32
+    assert torch.equal(dw, ops.conv3_wgrad(x, dy))
+    xr, dyr = torch.randn_like(x), torch.randn_like(dy)
+    assert torch.equal(ops.conv3_wgrad(xr, dyr), ops.conv3_wgrad(xr, dyr))   # no atomics: bit-stable
