@@ -397,6 +397,8 @@ def main():
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
 
     box = None if a.no_extra else bench_box_head(dev, world, rank, backend, barrier)      # all ranks: it holds collectives
+    det_train = None if (a.no_extra or a.no_model) else bench_detector_train(ops, synth, tab, dev, world, rank,
+                                                                             backend, barrier)
 
     result = None
     if rank == 0:
@@ -466,6 +468,8 @@ def main():
             result["strong_scaling"] = strong
         if box is not None:
             result["box_head_train"] = box
+        if det_train is not None:
+            result["detector_train"] = det_train
         if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line
             result["host_fed"] = bench_host_fed(ops, sb, tab, dev)
             result["cutout"] = bench_cutout(ops, synth, tab, dev, variants=not a.no_model)
@@ -553,6 +557,65 @@ def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
             "ms_per_step": dt * 1e3, "samples_per_s": world * per / dt, "per_rank_batch": per,
             "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": nbytes,
             "grad_allreduce_busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if ar_ms else None,
+            "collective_backend": backend if world > 1 else None}
+
+
+def bench_detector_train(ops, synth, tab, dev, world, rank, backend, barrier, steps=10, warm=3):
+    """BASELINE configs[2] in training -- "the detector's gradient step" of the north star: 8 windows of 5 scans x
+    450 points PER RANK -> area cutouts (HIP) -> DR-SPAAM (SpatialDROW, reference architecture, random init) in
+    training mode -> classification + regression loss -> backward -> ONE flat gradient all-reduce over RCCL ->
+    Adam.  The trunk (Conv1d + BatchNorm(train) + LeakyReLU + max-pool, forward / data / weight gradients) runs on
+    the HIP training kernels (torch_ops.TrunkUnitTrain), the gate on the HIP attention forward / backward; the
+    embedding GEMM and the 1x1 heads are hipBLASLt through torch.  Runs on every rank; rank 0 reports."""
+    import torch
+    import torch.distributed as dist
+    import torch.nn.functional as F
+    from planar_optical_flow_amd import dist as pdist
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    B, T, N, P = 8, 5, N_PTS, 56
+    torch.manual_seed(5)
+    model = SpatialDROW(num_scans=T, num_pts=P, alpha=0.5, window_size=11, pedestrian_only=True).to(dev)
+    if world > 1:
+        pdist.broadcast_parameters(model)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True)
+    reducer = pdist.GradientAllReduce(model)
+    sb = synth.make_batch(seed=50 + rank, B=B, T=T, N=N)
+    scans = torch.from_numpy(sb.scans).to(dev)
+    g = torch.Generator(device=dev).manual_seed(60 + rank)
+    tcls = (torch.rand((B, N, 1), device=dev, generator=g) < 0.1).float()
+    treg = torch.randn((B, N, 2), device=dev, generator=g) * 0.3
+    kw = dict(fixed=True, centered=True, window_width=1.0, window_depth=0.5, num_cutout_pts=P, padding_val=29.99,
+              area_mode=True)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        x = ops.cutout(scans, tab, **kw)
+        pred_cls, pred_reg, _ = model(x)
+        loss = F.binary_cross_entropy_with_logits(pred_cls, tcls) + F.mse_loss(pred_reg, treg)
+        loss.backward()
+        reducer()
+        opt.step()
+        return loss
+
+    for _ in range(warm):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    barrier()
+    dt = (time.perf_counter() - t0) / steps
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"workload": "BASELINE configs[2], training: DR-SPAAM step (cutout + forward + backward + gradient "
+                        "all-reduce + Adam), %d windows x %d scans x %d points per rank x %d rank(s)" % (B, T, N, world),
+            "ms_per_step": dt * 1e3, "scans_per_s": world * B / dt, "per_rank_batch": B,
+            "grad_bucket_bytes": reducer.bucket.numel() * 4,
+            "trunk": "HIP: conv3 forward / dgrad (conv3_kernel), wgrad (conv3_wgrad_kernel), BatchNorm(train) + "
+                     "LeakyReLU + max-pool forward / backward (bn_* kernels)",
             "collective_backend": backend if world > 1 else None}
 
 

@@ -199,24 +199,34 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv3_wgrad_kernel(WgradArgs a)
     }
 }
 
-// dw[co][ci][t] = sum over splits, float64 accumulation (a few hundred terms)
+// dw[co][ci][t] = sum over splits (float64 accumulation).  32 consecutive weights x 8 groups of splits per
+// workgroup: a few hundred splits of a small layer (64 x 64 weights) would otherwise be one serial chain per thread
 __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, int Co,
                                                                  int Ci, float *__restrict__ dw)
 {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= Co * Ci) return;
+    __shared__ double s_part[8][3][32];
+    const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
     const long long plane = (long long)Co * Ci;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    const float *p = partial + e;
+    if (e < plane) {
+        const float *p = partial + e + (long long)grp * 3 * plane;
 #pragma unroll 4
-    for (int k = 0; k < nsplit; ++k, p += 3 * plane) {
-        s0 += (double)p[0];
-        s1 += (double)p[plane];
-        s2 += (double)p[2 * plane];
+        for (int k = grp; k < nsplit; k += 8, p += 8 * 3 * plane) {
+            s0 += (double)p[0];
+            s1 += (double)p[plane];
+            s2 += (double)p[2 * plane];
+        }
     }
-    dw[3 * (long long)e + 0] = (float)s0;
-    dw[3 * (long long)e + 1] = (float)s1;
-    dw[3 * (long long)e + 2] = (float)s2;
+    s_part[grp][0][el] = s0; s_part[grp][1][el] = s1; s_part[grp][2][el] = s2;
+    __syncthreads();
+    if (threadIdx.x < 96) {
+        const int t = threadIdx.x >> 5;
+        double acc = 0.0;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) acc += s_part[g][t][el];
+        if (e < plane) dw[3 * (long long)e + t] = (float)acc;
+    }
 }
 
 bool make_wgrad(int S, int Ci, int Co, int L, bool aligned, WgradArgs *a, int *wm, size_t *lds_bytes)
@@ -294,7 +304,7 @@ extern "C" int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, i
     else { if (a.vec == 4) POF_WGRAD(2, 4); else if (a.vec == 2) POF_WGRAD(2, 2); else POF_WGRAD(2, 1); }
 #undef POF_WGRAD
     POF_CHECK_LAUNCH();
-    conv3_wgrad_reduce_kernel<<<(Co * Ci + 255) / 256, 256, 0, st>>>(a.partial, a.nsplit, Co, Ci, dw);
+    conv3_wgrad_reduce_kernel<<<(Co * Ci + 31) / 32, 256, 0, st>>>(a.partial, a.nsplit, Co, Ci, dw);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }
