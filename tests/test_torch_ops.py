@@ -269,3 +269,74 @@ def test_conv3_wgrad_exact_on_integer_data_and_deterministic():
     assert torch.equal(dw, ops.conv3_wgrad(x, dy))
     xr, dyr = torch.randn_like(x), torch.randn_like(dy)
     assert torch.equal(ops.conv3_wgrad(xr, dyr), ops.conv3_wgrad(xr, dyr))   # no atomics: bit-stable
+
+
+@pytest.mark.gpu
+def test_conv3_train_exact_on_integer_data():
+    """Forward and data gradient of the training convolution on small integers: every product and partial sum is
+    exact in float32, so the result must equal torch's float64 convolution exactly."""
+    from planar_optical_flow_amd import torch_ops
+    g = torch.Generator(device="cuda").manual_seed(9)
+    conv = torch.nn.Conv1d(64, 128, 3, padding=1).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randint(-2, 3, conv.weight.shape, device="cuda", generator=g).float())
+        conv.bias.copy_(torch.randint(-2, 3, conv.bias.shape, device="cuda", generator=g).float())
+    ref = torch.nn.Conv1d(64, 128, 3, padding=1).cuda().double()
+    ref.load_state_dict(conv.state_dict())
+    x = torch.randint(-3, 4, (90, 64, 28), device="cuda", generator=g).float().requires_grad_(True)
+    x64 = x.detach().double().requires_grad_(True)
+    y = torch_ops.conv3_train(x, conv)
+    y64 = ref(x64)
+    assert torch.equal(y.detach().double(), y64.detach())
+    gy = torch.randint(-2, 3, y.shape, device="cuda", generator=g).float()
+    y.backward(gy)
+    y64.backward(gy.double())
+    assert torch.equal(x.grad.double(), x64.grad)
+    assert torch.equal(conv.weight.grad.double(), ref.weight.grad)
+    assert torch.equal(conv.bias.grad.double(), ref.bias.grad)
+
+
+@pytest.mark.gpu
+def test_training_trunk_under_no_grad_and_frozen_weights():
+    """Training-mode statistics without autograd (BatchNorm calibration) and with frozen trunk weights
+    (FlowDROW_pretrained freezes DR-SPAAM): the fused unit runs forward only and still updates the running stats."""
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import DROW
+    torch.manual_seed(4)
+    m = DROW(num_scans=2).cuda().train()
+    ref = DROW(num_scans=2).cuda().train()
+    ref.load_state_dict(m.state_dict())
+    ref.fused_train_tail = False
+    for p in list(m.parameters()) + list(ref.parameters()):
+        p.requires_grad_(False)
+    x = torch.rand(2, 40, 2, 48, device="cuda") * 3
+    with torch.no_grad():
+        a = m(x)
+    b = ref(x)
+    assert torch.allclose(a[0], b[0], rtol=1e-3, atol=1e-4) and torch.allclose(a[1], b[1], rtol=1e-3, atol=1e-4)
+    for (n, p), q in zip(m.named_buffers(), ref.buffers()):
+        assert torch.allclose(p.double(), q.double(), rtol=1e-4, atol=1e-5), n
+
+
+@pytest.mark.gpu
+def test_training_trunk_compiles():
+    """torch.compile of a training step through the fused units: the custom ops carry fake kernels, the shape
+    probes are plain Python -- whatever the compiler makes of the frame, the step must agree with eager."""
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import DROW
+    torch.manual_seed(6)
+    m = DROW(num_scans=2).cuda().train()
+    ref = DROW(num_scans=2).cuda().train()
+    ref.load_state_dict(m.state_dict())
+    x = torch.rand(2, 40, 2, 48, device="cuda") * 3
+
+    def step(model, xx):
+        cls, reg = model(xx)
+        return cls.square().mean() + reg.square().mean()
+
+    loss_c = torch.compile(step)(m, x)
+    loss_c.backward()
+    loss_e = step(ref, x)
+    loss_e.backward()
+    assert torch.allclose(loss_c, loss_e, rtol=1e-4, atol=1e-6)
+    gscale = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
+    for (n, p), q in zip(m.named_parameters(), ref.parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-3 * gscale, n
