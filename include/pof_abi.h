@@ -396,7 +396,8 @@ int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int
  * the workspace, one reduction pass).  The forward and the data gradient of the same
  * convolution are pof_conv3_bn_lrelu with unit scale / slope 1 (data gradient: dy as
  * input, taps reversed, channel roles swapped).
- * workspace: pof_conv3_wgrad_workspace_bytes(S, Ci, Co, L) bytes (0 = unsupported: L > ~90).
+ * workspace: pof_conv3_wgrad_workspace_bytes(S, Ci, Co, L) bytes (0 = unsupported shape: rows longer
+ * than 64 positions, or odd rows longer than 32 -- callers keep their library path for those).
  * ---------------------------------------------------------------------- */
 size_t pof_conv3_wgrad_workspace_bytes(int S, int Ci, int Co, int L);
 int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, float *dw,

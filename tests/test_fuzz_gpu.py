@@ -357,3 +357,71 @@ def test_fuzz_standalone_geometry_and_store(ops, seed):
         w0, w1 = R.associate_odometry(t_o, t_s, int(idx[k]), inds)
         assert (int(i0[k]), int(i1[k])) == (w0, w1)
         assert np.array_equal(od1[k].cpu().numpy(), odoms[w1].astype(np.float64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(12 * _SCALE))
+def test_fuzz_training_trunk_kernels(ops, seed):
+    """N2 training kernels on random shapes (ragged channel counts, odd lengths, sequence counts that leave the
+    last chunk / stage / split partly empty): fused BatchNorm(train) tail forward + backward against torch in
+    float64, split-K weight gradient and the conv forward / data gradient against float64 conv1d."""
+    import torch
+    rng = np.random.default_rng(9000 + seed)
+    g = torch.Generator(device="cuda").manual_seed(9000 + seed)
+    # ---- tail
+    L = int(rng.choice([2, 4, 6, 7, 8, 12, 14, 24, 28, 30, 48, 56, 64, 100]))
+    C = int(rng.integers(1, 40)) * 4 if L % 4 else int(rng.integers(1, 160))
+    if (C * L) % 4:
+        C *= 4
+    S = int(rng.integers(1, 400))
+    pool = bool(rng.integers(0, 2)) and L % 2 == 0
+    slope = float(rng.choice([0.1, 0.01, 0.3]))
+    y = (torch.randn(S, C, L, device="cuda", generator=g) * float(rng.uniform(0.5, 3)) + float(rng.uniform(-2, 2)))
+    gam = torch.rand(C, device="cuda", generator=g) + 0.5
+    bet = torch.rand(C, device="cuda", generator=g) - 0.5
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    z, mu, istd = ops.bn_lrelu_pool_forward(y, gam, bet, rm, rv, momentum=0.1, eps=1e-5, negative_slope=slope, pool=pool)
+    y64 = y.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm64, rv64 = torch.zeros(C, device="cuda", dtype=torch.float64), torch.ones(C, device="cuda", dtype=torch.float64)
+    u = torch.nn.functional.batch_norm(y64, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+    z64 = torch.nn.functional.leaky_relu(u, slope)
+    if pool:
+        z64 = torch.max_pool1d(z64, 2)
+    assert torch.allclose(z.double(), z64, rtol=1e-5, atol=3e-5)
+    if S * L > 1:
+        assert torch.allclose(rv.double(), rv64, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(rm.double(), rm64, rtol=1e-5, atol=1e-6)
+    dz = torch.randn(z.shape, device="cuda", generator=g)
+    z64.backward(dz.double())
+    dy, dgam, dbet, dsum = ops.bn_lrelu_pool_backward(y, dz, gam, bet, mu, istd, negative_slope=slope, pool=pool,
+                                                      bias_grad=True)
+    # near a zero of u or a pooled tie the float32 forward may pick the other branch than float64 does: compare
+    # where the float64 pre-activation is clear of both
+    scale = max(float(y64.grad.abs().max()), 1e-3)
+    bad = (dy.double() - y64.grad).abs() > 1e-4 * scale
+    assert float(bad.double().mean()) < 2e-4
+    assert float((dgam.double() - g64.grad).abs().max()) <= 2e-3 * max(float(g64.grad.abs().max()), 1.0)
+    assert float((dbet.double() - b64.grad).abs().max()) <= 2e-3 * max(float(b64.grad.abs().max()), 1.0)
+    assert float((dsum.double() - dy.double().sum(dim=(0, 2))).abs().max()) <= 1e-4 * max(float(dy.abs().sum(dim=(0, 2)).max()), 1.0)
+    # ---- convolution passes
+    Lc = int(rng.choice([3, 6, 7, 9, 12, 14, 17, 24, 28, 33, 48, 56, 64]))
+    Ci, Co = int(rng.integers(1, 200)), int(rng.integers(1, 200))
+    Sc = int(rng.integers(1, 120))
+    x = torch.randn(Sc, Ci, Lc, device="cuda", generator=g)
+    gy = torch.randn(Sc, Co, Lc, device="cuda", generator=g)
+    w = (torch.randn(Co, Ci, 3, device="cuda", generator=g) * 0.2)
+    x64 = x.double().requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    yc64 = torch.nn.functional.conv1d(x64, w64, padding=1)
+    yc64.backward(gy.double())
+    from planar_optical_flow_amd import torch_ops
+    assert ops.conv3_wgrad_supported(Sc, Ci, Co, Lc) == (Lc % 2 == 0 or Lc <= 32)   # long odd rows: the library's
+    dw = torch_ops._weight_grad(x, gy, w)
+    assert float((dw.double() - w64.grad).abs().max()) <= 3e-5 * max(float(w64.grad.abs().max()), 1.0)
+    one, zero = torch.ones(Co, device="cuda"), torch.zeros(Co, device="cuda")
+    yc = ops.conv3_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), one, zero, pool=False, negative_slope=1.0)
+    assert float((yc.double() - yc64.detach()).abs().max()) <= 3e-5 * max(float(yc64.detach().abs().max()), 1.0)
+    dx = ops.conv3_bn_lrelu(gy, w.flip(2).permute(2, 0, 1).contiguous(), torch.ones(Ci, device="cuda"),
+                            torch.zeros(Ci, device="cuda"), pool=False, negative_slope=1.0)
+    assert float((dx.double() - x64.grad).abs().max()) <= 3e-5 * max(float(x64.grad.abs().max()), 1.0)
