@@ -551,10 +551,34 @@ def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    graphed = None
+    if world == 1:
+        # the same step as ONE hipGraph replay (graph_step.GraphedTrainStep): ~150 small kernels, eager pacing is the
+        # host's.  Single process only: with more ranks the step holds collectives (SyncBatchNorm in the forward),
+        # which are not captured.
+        from planar_optical_flow_amd.graph_step import GraphedTrainStep
+        torch.manual_seed(4)
+        gmodel = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).to(dev).train()
+        goptim = Optim(gmodel, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
+        gstep = GraphedTrainStep(gmodel, goptim.make_capturable(), {"input": x, "target": y})
+        batch = {"input": x, "target": y}
+        for _ in range(warm):
+            goptim.set_lr(0)
+            gstep(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10 * steps):
+            goptim.set_lr(0)
+            gstep(batch)
+        torch.cuda.synchronize()
+        gdt = (time.perf_counter() - t0) / (10 * steps)
+        graphed = {"ms_per_step": gdt * 1e3, "samples_per_s": per / gdt,
+                   "note": "zero_grad + forward + backward + Adam captured once, replayed per batch (inputs copied "
+                           "into static buffers, learning rate a device scalar)"}
     nbytes = reducer.bucket.numel() * 4
     return {"workload": "BASELINE configs[3]: box-regression head training step, batch 256 per rank x %d rank(s), "
                         "64-point segments, Adam(amsgrad), one flat gradient all-reduce, global-batch BatchNorm" % world,
-            "ms_per_step": dt * 1e3, "samples_per_s": world * per / dt, "per_rank_batch": per,
+            "ms_per_step": dt * 1e3, "samples_per_s": world * per / dt, "per_rank_batch": per, "graphed": graphed,
             "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": nbytes,
             "grad_allreduce_busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if ar_ms else None,
             "collective_backend": backend if world > 1 else None}

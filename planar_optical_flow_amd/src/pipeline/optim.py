@@ -30,10 +30,22 @@ class Optim:
     def set_lr(self, epoch):
         lr = exp_decay_lr(epoch, **self._schedule)
         for group in self._optim.param_groups:
-            group["lr"] = lr
+            if torch.is_tensor(group["lr"]):      # capturable form: a device scalar the captured step reads
+                group["lr"].fill_(lr)
+            else:
+                group["lr"] = lr
+        self._lr = lr
 
     def get_lr(self):
-        return self._optim.param_groups[0]["lr"]
+        lr = self._optim.param_groups[0]["lr"]
+        return getattr(self, "_lr", float(lr)) if torch.is_tensor(lr) else lr
+
+    def make_capturable(self):
+        """Device-resident step counters and learning rate, so that ``step()`` can be captured in a hipGraph
+        (planar_optical_flow_amd.graph_step).  Before the first step only."""
+        from planar_optical_flow_amd.graph_step import make_capturable
+        make_capturable(self._optim)
+        return self._optim
 
 
 class _ExpDecayScheduler:

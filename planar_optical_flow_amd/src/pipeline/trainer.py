@@ -27,6 +27,10 @@ class Trainer:
         self._stop = False
         self._reducer = None
         self._sync_bn = bool(cfg.get("sync_bn", True))
+        # graph_step: capture zero_grad / forward / backward / clip / Adam of a fixed-shape batch as one hipGraph and
+        # replay it per batch (single process, model on the GPU); the last, shorter batch of an epoch runs eagerly
+        self._graph_step = bool(cfg.get("graph_step", False))
+        self._graphed, self._graphed_shapes = None, None
         self._dist_ready = False
         try:
             signal.signal(signal.SIGINT, self._on_signal)
@@ -92,10 +96,32 @@ class Trainer:
             self._logger.flush()
         return 0
 
+    def _graph_shapes(self, batch):
+        return tuple((k, tuple(batch[k].shape)) for k in ("input", "target"))
+
+    def _train_batch_graphed(self, model, batch, ratio):
+        from planar_optical_flow_amd.graph_step import GraphedTrainStep
+        if self._graphed is None:
+            if self._step != 0:
+                raise RuntimeError("graph_step has to be on from the first step (the optimiser state must be capturable)")
+            optim = self._optim.make_capturable()
+            self._graphed = GraphedTrainStep(model, optim, batch, grad_norm_clip=self._grad_norm_clip)
+            self._graphed_shapes = self._graph_shapes(batch)
+        self._optim.set_lr(self._epoch + ratio)
+        loss = self._graphed.step(batch).item()
+        self._logger.add_scalar("TRAIN_lr", self._optim.get_lr(), self._step)
+        self._logger.add_scalar("TRAIN_loss", loss, self._step)
+        self._logger.add_scalar("TRAIN_epoch", self._epoch + ratio, self._step)
+        return loss
+
     def _train_batch(self, model, batch, ratio):
         self._prepare_distributed(model)
         model.train()
-        self._optim.zero_grad()
+        if self._graph_step and self._reducer is None and next(model.parameters()).is_cuda \
+                and (self._graphed is None or self._graph_shapes(batch) == self._graphed_shapes):
+            return self._train_batch_graphed(model, batch, ratio)
+        # once a step is captured its graph owns the addresses of the gradient buffers: keep them allocated
+        self._optim.zero_grad(set_to_none=self._graphed is None)
         self._optim.set_lr(self._epoch + ratio)
         loss, tb_dict, _ = model.model_fn(model, batch)
         loss.backward()
