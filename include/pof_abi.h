@@ -364,6 +364,17 @@ int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, cons
                        pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * N2 detector heads, inference                  src/depracted/model/dr_spaam.py:104-121
+ * pred_cls[s][o] = b_cls[o] + sum_c w_cls[o][c] * mean_l feat[s][c][l]   (o < n_cls <= 6)
+ * pred_reg[s][o] = b_reg[o] + sum_c w_reg[o][c] * mean_l feat[s][c][l]   (o < 2)
+ * -- the average pool over the last block's positions and the two 1x1 convolutions
+ * (conv_cls [n_cls][C][1], conv_reg [2][C][1]) in one launch.  feat [S][C][L] float32.
+ * ---------------------------------------------------------------------- */
+int pof_drow_heads(const float *feat, int S, int C, int L, const float *w_cls, const float *b_cls,
+                   int n_cls, const float *w_reg, const float *b_reg, float *pred_cls,
+                   float *pred_reg, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N2 trunk unit tail, training                  src/depracted/model/dr_spaam.py:8-19, :86-92
  * z = max_pool1d?(LeakyReLU(BatchNorm1d_train(y)), 2) and its backward pass, for the
  * convolution output y [S][C][L] float32 (L <= 256, C*L % 4 == 0, L even when pooled):

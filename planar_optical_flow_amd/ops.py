@@ -351,6 +351,26 @@ def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None
     return out
 
 
+def drow_heads(feat, w_cls, b_cls, w_reg, b_reg):
+    """N2 heads (inference): feat [S,C,L] f32, w_cls [n_cls,C], w_reg [2,C] -> (pred_cls [S,n_cls], pred_reg [S,2]):
+    mean over positions + both 1x1 convolutions in one launch."""
+    feat = _dev(feat, torch.float32, "feat")
+    S, C, L = feat.shape
+    w_cls = _dev(w_cls.reshape(-1, C), torch.float32, "w_cls")
+    w_reg = _dev(w_reg.reshape(-1, C), torch.float32, "w_reg")
+    b_cls, b_reg = _dev(b_cls, torch.float32, "b_cls"), _dev(b_reg, torch.float32, "b_reg")
+    n_cls = w_cls.shape[0]
+    if w_reg.shape[0] != 2 or b_cls.numel() != n_cls or b_reg.numel() != 2:
+        raise ValueError("heads: w_cls [n_cls, C], b_cls [n_cls], w_reg [2, C], b_reg [2]")
+    pred_cls = torch.empty((S, n_cls), dtype=torch.float32, device=feat.device)
+    pred_reg = torch.empty((S, 2), dtype=torch.float32, device=feat.device)
+    if S > 0:
+        with torch.cuda.device(feat.device):
+            _lib.call("pof_drow_heads", _ptr(feat), S, C, L, _ptr(w_cls), _ptr(b_cls), n_cls, _ptr(w_reg), _ptr(b_reg),
+                      _ptr(pred_cls), _ptr(pred_reg), _stream())
+    return pred_cls, pred_reg
+
+
 def conv3_wgrad_supported(S, Ci, Co, L):
     return S > 0 and int(_lib.load().pof_conv3_wgrad_workspace_bytes(int(S), int(Ci), int(Co), int(L))) > 0
 

@@ -52,7 +52,31 @@ class _SpatialAttention(nn.Module):
         [B*N, C*P] x [C*P, 128]: run it as one library GEMM (same parameters, same gradients) instead of
         a convolution, then the module's own BatchNorm and LeakyReLU."""
         conv, bn, act = self.conv[0], self.conv[1], self.conv[2]
+        folded = getattr(self, "_folded", None)
+        if folded is not None and not self.training and not torch.is_grad_enabled():
+            # inference after fold_for_inference(): the BatchNorm lives in the GEMM's weights and bias -- two launches
+            # (GEMM with bias, LeakyReLU) instead of five; a launch costs ~5 us in the streaming step's graph
+            return torch.nn.functional.leaky_relu(torch.nn.functional.linear(flat, folded[0], folded[1]),
+                                                  act.negative_slope)
         return act(bn(torch.nn.functional.linear(flat, conv.weight.reshape(conv.out_channels, -1), conv.bias)))
+
+    def fold_for_inference(self, enable=True):
+        """Fold the embedding's BatchNorm (running statistics) into its weight and bias.  Call after loading a
+        checkpoint (``DROW.fuse_for_inference`` does); ``train()`` drops the folded copy."""
+        self._folded = None
+        if enable:
+            conv, bn = self.conv[0], self.conv[1]
+            with torch.no_grad():
+                scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                w = (conv.weight.reshape(conv.out_channels, -1) * scale[:, None]).contiguous()
+                b = (bn.bias + (conv.bias - bn.running_mean) * scale).contiguous()
+            self._folded = (w, b)
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            self._folded = None
+        return super().train(mode)
 
     def forward(self, x, x_template):
         """x, x_template [B, n_cutout, n_channel, n_pts] -> (fused template of the
@@ -121,6 +145,8 @@ class DROW(nn.Module):
         implicit GEMMs instead of MIOpen convolutions.  Training mode always uses the torch modules."""
         self._fused = None
         if not enable:
+            if getattr(self, "gate", None) is not None:
+                self.gate.fold_for_inference(False)
             return self
         fused = {}
         with torch.no_grad():
@@ -134,6 +160,9 @@ class DROW(nn.Module):
                                    shift.float().contiguous()))
                 fused[name] = layers
         self._fused = fused
+        gate = getattr(self, "gate", None)
+        if gate is not None:
+            gate.fold_for_inference(True)
         return self
 
     def train(self, mode=True):
@@ -246,6 +275,12 @@ class DROW(nn.Module):
         # average over the remaining positions, then the two 1x1 convolutions -- on a length-1 sequence
         # they are dense layers: issue them as library GEMMs (MIOpen runs 1x1 convs on [B*N, 128, 1]
         # through its naive kernel)
+        if getattr(self, "_fused", None) is not None and not self.training and out.is_cuda \
+                and not torch.is_grad_enabled() and self.conv_cls.out_channels <= 6:
+            # inference after fuse_for_inference(): mean + both heads in one launch (pof_drow_heads)
+            pred_cls, pred_reg = ops.drow_heads(out.contiguous().float(), self.conv_cls.weight, self.conv_cls.bias,
+                                                self.conv_reg.weight, self.conv_reg.bias)
+            return pred_cls.view(B, N, -1), pred_reg.view(B, N, 2)
         feat = out.mean(dim=-1)
         lin = torch.nn.functional.linear
         pred_cls = lin(feat, self.conv_cls.weight.squeeze(-1), self.conv_cls.bias)

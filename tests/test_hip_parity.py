@@ -864,3 +864,19 @@ def test_config5_band_correlation_n450_f16(ops):
     got = ops.band_correlation(T(f1), T(f2), 3, 5).cpu().numpy()
     want = R.band_correlation(f1.astype(np.float64), f2.astype(np.float64), 3, 5)
     np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C,L,ncls", [(450, 128, 7, 1), (37, 128, 6, 4), (5, 96, 3, 2), (1, 200, 1, 1)])
+def test_drow_heads_match_mean_and_linears(S, C, L, ncls):
+    """N2 heads in one launch against mean over positions + the two dense layers in float64."""
+    import torch
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + C)
+    feat = torch.randn(S, C, L, device="cuda", generator=g)
+    wc, bc = torch.randn(ncls, C, 1, device="cuda", generator=g), torch.randn(ncls, device="cuda", generator=g)
+    wr, br = torch.randn(2, C, 1, device="cuda", generator=g), torch.randn(2, device="cuda", generator=g)
+    cls, reg = ops.drow_heads(feat, wc, bc, wr, br)
+    m = feat.double().mean(dim=-1)
+    assert torch.allclose(cls.double(), m @ wc.double().squeeze(-1).T + bc.double(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(reg.double(), m @ wr.double().squeeze(-1).T + br.double(), rtol=1e-5, atol=1e-5)
