@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--no-model", action="store_true",
                     help="skip the DR-SPAAM forward extra (PMC passes: keeps the per-kernel averages per shape)")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training-step rows (box head incl. its hipGraph replay, detector): the rocprofv3 "
+                         "--pmc passes leave them out -- counter collection aborts the queue on the captured step")
     ap.add_argument("--repeats", type=int, default=5, help="timed repeats of the K-step region (median reported)")
     ap.add_argument("--spawn", action="store_true", help="start the rank processes from this one even for --gpus 1")
     return ap.parse_args()
@@ -396,8 +399,8 @@ def main():
         ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
 
-    box = None if a.no_extra else bench_box_head(dev, world, rank, backend, barrier)      # all ranks: it holds collectives
-    det_train = None if (a.no_extra or a.no_model) else bench_detector_train(ops, synth, tab, dev, world, rank,
+    box = None if (a.no_extra or a.no_train) else bench_box_head(dev, world, rank, backend, barrier)      # all ranks: it holds collectives
+    det_train = None if (a.no_extra or a.no_model or a.no_train) else bench_detector_train(ops, synth, tab, dev, world, rank,
                                                                              backend, barrier)
 
     result = None
