@@ -286,6 +286,18 @@ int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const
                                    float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
                                    float *d_tmpl, pof_stream_t stream);
 
+/* The same gradients with the two large passes fused (one walk over g and tmpl: the algorithmic
+ * 4 * N * F * 4 bytes instead of reading g and tmpl twice).  workspace:
+ * pof_spatial_attention_backward_workspace_bytes(B, N, F, window) bytes of per-column-block partial
+ * band products (deterministic: summed in a fixed order by a finishing pass). */
+size_t pof_spatial_attention_backward_workspace_bytes(int B, int N, int F, int window);
+int pof_spatial_attention_backward_fused(const float *emb_x, const float *emb_t, const float *tmpl,
+                                         const float *prob, const float *g_out, const float *g_band,
+                                         int B, int N, int E, int F, int window, double alpha,
+                                         float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
+                                         float *d_tmpl, void *workspace, size_t workspace_bytes,
+                                         pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A13 jump-distance segmentation + per-segment least squares
  *   src/depracted/model/adaboost_person_det.py:71-90 (cuts), :102-210 (features)

@@ -47,6 +47,8 @@ SIGNATURES = {
     "pof_band_correlation_f16": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "pof_spatial_attention_f16": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "pof_band_correlation_backward": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "pof_spatial_attention_backward_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "pof_spatial_attention_backward_fused": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_spatial_attention_backward": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p, _p, _p]),
     "pof_spatial_attention": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p, _p, _p]),
     "pof_segment_features": (_i, [_p, _p, _i, _i, _d, _i, _p, _p, _p, _p]),

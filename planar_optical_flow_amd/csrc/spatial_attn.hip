@@ -517,6 +517,188 @@ extern "C" int pof_spatial_attention_f16(const float *emb_x, const float *emb_t,
                                      static_cast<_Float16 *>(out_f16), stream);
 }
 
+namespace {
+
+// ---- backward, fused form -------------------------------------------------------------------------
+// The two large passes of the backward both read the output gradient g: the transposed merge (d tmpl, d x) and the
+// band product dp[i][k] = <g[i], tmpl[i-hw+k]>.  Here they are ONE walk down the points: a lane owns one 16-byte
+// column of the rows and keeps two W-deep register rings, of g rows (for d tmpl, as the transposed merge does) and
+// of tmpl rows; at point i the W dot products of its 4 columns are summed over the wave's 64 lanes and lane 0
+// writes them to partial[column block][b][i][k].  g, tmpl are read once, d tmpl, d x written once: the
+// algorithmic 4 * N * F * 4 bytes (the two-pass form reads g twice and tmpl twice).  A small finishing pass sums
+// the column blocks in a fixed order (deterministic, no atomics) and runs the softmax backward of each row.
+template <int W>
+__global__ __launch_bounds__(128) void attn_bwd_fused_kernel(const float4 *__restrict__ g, const float4 *__restrict__ tmpl,
+                                                             const float *__restrict__ prob, float4 *__restrict__ d_tmpl,
+                                                             float4 *__restrict__ d_x, float *__restrict__ partial,
+                                                             int B, int N, int F4, int L, float alpha,
+                                                             float one_minus_alpha)
+{
+    constexpr int HW = W / 2;
+    const int col = blockIdx.x * 128 + threadIdx.x;
+    const bool active = col < F4;                     // inactive lanes stay for the wave sums, contribute zeros
+    const int colc = active ? col : F4 - 1;
+    const int b = blockIdx.z;
+    const int s0 = blockIdx.y * L;
+    const int s1 = min(N, s0 + L);
+    const long long sample = (long long)b * N;
+    const float4 *G = g + sample * F4 + colc;
+    const float4 *Tm = tmpl + sample * F4 + colc;
+    float4 *DT = d_tmpl + sample * F4 + colc;
+    float4 *DX = d_x + sample * F4 + colc;
+    const float *P = prob + sample * W;
+    const int cb = blockIdx.x * 2 + (threadIdx.x >> 6);            // column block = one wave = 256 floats of a row
+    float *part = partial + ((long long)cb * B + b) * N * W;
+    const int lane = threadIdx.x & 63;
+    const int base = s0 - HW;
+    const int rmax = s1 - 1 + HW;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 win[W], twin[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) { win[u] = zero; twin[u] = zero; }
+
+    for (int m = 0; base + m * W <= rmax; ++m) {
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+            const int r = base + m * W + u;
+            if (r <= rmax) {
+                const bool in = r >= 0 && r <= N - 1 && active;
+                win[u] = in ? G[(long long)r * F4] : zero;
+                twin[u] = in ? Tm[(long long)r * F4] : zero;
+                const int i = r - HW;
+                if (i >= s0) {
+                    float4 acc = zero;
+                    const float4 gv = win[(u + HW + 1) % W];          // row i of g
+                    float dp[W];
+#pragma unroll
+                    for (int k = 0; k < W; ++k) {
+                        const int src = i - HW + k;   // row whose window contains column i at slot W-1-k
+                        const float pk = (src >= 0 && src <= N - 1) ? P[(long long)src * W + (W - 1 - k)] : 0.0f;
+                        const float4 t = win[(u + k + 1) % W];
+                        acc.x = fmaf(pk, t.x, acc.x);
+                        acc.y = fmaf(pk, t.y, acc.y);
+                        acc.z = fmaf(pk, t.z, acc.z);
+                        acc.w = fmaf(pk, t.w, acc.w);
+                        const float4 tt = twin[(u + k + 1) % W];       // tmpl row i - HW + k
+                        dp[k] = fmaf(gv.w, tt.w, fmaf(gv.z, tt.z, fmaf(gv.y, tt.y, gv.x * tt.x)));
+                    }
+                    if (active) {
+                        stream_store<float>(reinterpret_cast<Col4<float> *>(DX + (long long)i * F4),
+                                            make_float4(alpha * gv.x, alpha * gv.y, alpha * gv.z, alpha * gv.w));
+                        stream_store<float>(reinterpret_cast<Col4<float> *>(DT + (long long)i * F4),
+                                            make_float4(one_minus_alpha * acc.x, one_minus_alpha * acc.y,
+                                                        one_minus_alpha * acc.z, one_minus_alpha * acc.w));
+                    }
+#pragma unroll
+                    for (int k = 0; k < W; ++k) dp[k] = wave_sum_f32(dp[k]);
+                    if (lane == 0) {
+#pragma unroll
+                        for (int k = 0; k < W; ++k) part[(long long)i * W + k] = dp[k];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// dsim[i][k] = p * (dp - sum_k p dp) + g_band, dp = (1 - alpha) * sum over the column blocks (in order)
+__global__ __launch_bounds__(256) void attn_dsim_finish_kernel(const float *__restrict__ partial, int ncb,
+                                                               const float *__restrict__ prob,
+                                                               const float *__restrict__ g_band, long long rows, int N,
+                                                               int W, float one_minus_alpha, float *__restrict__ dsim)
+{
+    const long long row = (long long)blockIdx.x * 256 + threadIdx.x;      // (b, i)
+    if (row >= rows) return;
+    const int i = (int)(row % N), hw = W / 2;
+    float dp[kMaxW];
+    float s = 0.0f;
+    for (int k = 0; k < W; ++k) {
+        float v = 0.0f;
+        for (int c = 0; c < ncb; ++c) v += partial[((long long)c * rows + row) * W + k];
+        const int j = i - hw + k;            // unclamped column: out-of-range slots carry no weight
+        dp[k] = (j >= 0 && j <= N - 1) ? v * one_minus_alpha : 0.0f;
+        s = fmaf(prob[row * W + k], dp[k], s);
+    }
+    for (int k = 0; k < W; ++k)
+        dsim[row * W + k] = prob[row * W + k] * (dp[k] - s) + (g_band ? g_band[row * W + k] : 0.0f);
+}
+
+template <int W>
+void launch_bwd_fused(const float *g, const float *tmpl, const float *prob, float *d_tmpl, float *d_x, float *partial,
+                      int B, int N, int F, int L, double alpha, hipStream_t s)
+{
+    const int F4 = F / 4;
+    dim3 grid((F4 + 127) / 128, (N + L - 1) / L, B);
+    attn_bwd_fused_kernel<W><<<grid, 128, 0, s>>>(reinterpret_cast<const float4 *>(g),
+                                                  reinterpret_cast<const float4 *>(tmpl), prob,
+                                                  reinterpret_cast<float4 *>(d_tmpl), reinterpret_cast<float4 *>(d_x),
+                                                  partial, B, N, F4, L, (float)alpha, (float)(1.0 - alpha));
+}
+
+}  // namespace
+
+extern "C" size_t pof_spatial_attention_backward_workspace_bytes(int B, int N, int F, int window)
+{
+    const int W = 2 * (window / 2) + 1;
+    if (B < 1 || N < 1 || F < 4 || W < 1) return 0;
+    const size_t ncb = 2 * (size_t)((F / 4 + 127) / 128);
+    return ncb * (size_t)B * N * W * sizeof(float);
+}
+
+extern "C" int pof_spatial_attention_backward_fused(const float *emb_x, const float *emb_t, const float *tmpl,
+                                                    const float *prob, const float *g_out, const float *g_band,
+                                                    int B, int N, int E, int F, int window, double alpha,
+                                                    float *dsim, float *d_emb_x, float *d_emb_t, float *d_x,
+                                                    float *d_tmpl, void *workspace, size_t workspace_bytes,
+                                                    pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (!emb_x || !emb_t || !tmpl || !prob || !g_out || !dsim || !d_emb_x || !d_emb_t || !d_x || !d_tmpl || !workspace)
+        return POF_E_BADARG;
+    if (B < 0 || N < 1 || E < 1 || F < 1) return POF_E_BADARG;
+    const int W = 2 * (window / 2) + 1;
+    if (W < 1 || W > kMaxW) return POF_E_SHAPE;
+    if (F % 4 != 0) return POF_E_SHAPE;
+    if (B == 0) return POF_OK;
+    if (B > 65535) return POF_E_SHAPE;
+    if (workspace_bytes < pof_spatial_attention_backward_workspace_bytes(B, N, F, window)) return POF_E_WORKSPACE;
+    hipStream_t s = pof_stream(stream);
+    float *partial = static_cast<float *>(workspace);
+    const int ncb = 2 * ((F / 4 + 127) / 128);
+    {
+        // segment length as for the merge kernel: whole scan per lane when the batch alone fills the chip
+        const long long colblocks = (F / 4 + 127) / 128;
+        int L = N;
+        while (L > 32 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
+        switch (W) {
+            case 1: launch_bwd_fused<1>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 3: launch_bwd_fused<3>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 5: launch_bwd_fused<5>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 7: launch_bwd_fused<7>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 9: launch_bwd_fused<9>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 11: launch_bwd_fused<11>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 13: launch_bwd_fused<13>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            case 15: launch_bwd_fused<15>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
+            default: return POF_E_SHAPE;
+        }
+    }
+    POF_CHECK_LAUNCH();
+    {
+        const long long rows = (long long)B * N;
+        attn_dsim_finish_kernel<<<(unsigned)((rows + 255) / 256), 256, 0, s>>>(partial, ncb, prob, g_band, rows, N, W,
+                                                                              (float)(1.0 - alpha), dsim);
+    }
+    POF_CHECK_LAUNCH();
+    {
+        const int ec = E < kDeChunk ? E : kDeChunk;
+        const size_t lds = ((size_t)2 * (kDeTile + W - 1) * ec + (size_t)(kDeTile + W - 1) * W + (size_t)kDeTile * W) * sizeof(float);
+        attn_demb_kernel<<<dim3((N + kDeTile - 1) / kDeTile, B, (E + kDeChunk - 1) / kDeChunk), 256, lds, s>>>(
+            emb_x, emb_t, dsim, N, E, W, d_emb_x, d_emb_t);
+    }
+    POF_CHECK_LAUNCH();
+    return POF_OK;
+}
+
 extern "C" int pof_spatial_attention_backward(const float *emb_x, const float *emb_t, const float *tmpl,
                                               const float *prob, const float *g_out, const float *g_band,
                                               int B, int N, int E, int F, int window, double alpha,

@@ -639,8 +639,9 @@ def band_correlation_backward(feat1, feat2, g_out, kernel_size=3, max_displaceme
     return d1, d2
 
 
-def spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out, g_band, alpha, window_size):
-    """Gradients of spatial_attention: -> (d_emb_x, d_emb_t, d_x, d_tmpl)."""
+def spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out, g_band, alpha, window_size, fused=True):
+    """Gradients of spatial_attention: -> (d_emb_x, d_emb_t, d_x, d_tmpl).  ``fused``: one walk over g and tmpl
+    (pof_spatial_attention_backward_fused); False: the two-pass form (band product on the MFMA, transposed merge)."""
     emb_x = _dev(emb_x, torch.float32, "emb_x")
     emb_t = _dev(emb_t, torch.float32, "emb_t")
     tmpl = _dev(tmpl, torch.float32, "tmpl")
@@ -657,11 +658,16 @@ def spatial_attention_backward(emb_x, emb_t, tmpl, prob, g_out, g_band, alpha, w
     with torch.cuda.device(dev):
         for s in range(0, B, 65535):
             m = min(65535, B - s)
-            _lib.call("pof_spatial_attention_backward", _ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]),
-                      _ptr(tmpl[s:s + m]), _ptr(prob[s:s + m]), _ptr(g_out[s:s + m]),
-                      _ptr(g_band[s:s + m]) if g_band is not None else None, m, N, E, F, int(window_size),
-                      float(alpha), _ptr(dsim[s:s + m]), _ptr(dex[s:s + m]), _ptr(det[s:s + m]),
-                      _ptr(dx[s:s + m]), _ptr(dt[s:s + m]), _stream())
+            args = (_ptr(emb_x[s:s + m]), _ptr(emb_t[s:s + m]), _ptr(tmpl[s:s + m]), _ptr(prob[s:s + m]),
+                    _ptr(g_out[s:s + m]), _ptr(g_band[s:s + m]) if g_band is not None else None, m, N, E, F,
+                    int(window_size), float(alpha), _ptr(dsim[s:s + m]), _ptr(dex[s:s + m]), _ptr(det[s:s + m]),
+                    _ptr(dx[s:s + m]), _ptr(dt[s:s + m]))
+            if fused:
+                nbytes = int(_lib.load().pof_spatial_attention_backward_workspace_bytes(m, N, F, int(window_size)))
+                ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+                _lib.call("pof_spatial_attention_backward_fused", *args, _ptr(ws), nbytes, _stream())
+            else:
+                _lib.call("pof_spatial_attention_backward", *args, _stream())
     return dex, det, dx, dt
 
 

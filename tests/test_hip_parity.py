@@ -880,3 +880,30 @@ def test_drow_heads_match_mean_and_linears(S, C, L, ncls):
     m = feat.double().mean(dim=-1)
     assert torch.allclose(cls.double(), m @ wc.double().squeeze(-1).T + bc.double(), rtol=1e-5, atol=1e-5)
     assert torch.allclose(reg.double(), m @ wr.double().squeeze(-1).T + br.double(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,E,F,w", [(3, 450, 128, 3584, 11), (2, 57, 32, 200, 7), (5, 33, 16, 4, 3), (1, 450, 64, 1032, 15)])
+def test_spatial_attention_backward_fused_equals_two_pass(B, N, E, F, w):
+    """The fused backward (one walk over g and tmpl, per-column-block partial band products) against the two-pass
+    form (MFMA band product + transposed merge): d x and d tmpl bit-identical (same operations), the embedding
+    gradients to rounding (the band product is summed in another order)."""
+    import torch
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + N)
+    ex = torch.randn((B, N, E), device="cuda", generator=g) * 0.3
+    et = torch.randn((B, N, E), device="cuda", generator=g) * 0.3
+    x = torch.randn((B, N, F), device="cuda", generator=g)
+    t = torch.randn((B, N, F), device="cuda", generator=g)
+    out, band, prob = ops.spatial_attention(ex, et, x, t, 0.5, w)
+    go, gb = torch.randn(out.shape, device="cuda", generator=g), torch.randn(band.shape, device="cuda", generator=g)
+    ref = ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, w, fused=False)
+    got = ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, w, fused=True)
+    assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3])
+    for a, b in zip(got[:2], ref[:2]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1.0)
+    got2 = ops.spatial_attention_backward(ex, et, t, prob, go, None, 0.5, w, fused=True)
+    ref2 = ops.spatial_attention_backward(ex, et, t, prob, go, None, 0.5, w, fused=False)
+    for a, b in zip(got2[:2], ref2[:2]):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1.0)
+    assert torch.equal(ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, w)[0], got[0])   # deterministic

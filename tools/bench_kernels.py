@@ -72,9 +72,11 @@ if "bwd" in which:
         t = torch.randn((B, N, F), device=dev, generator=gen)
         out, band, prob = ops.spatial_attention(ex, et, x, t, 0.5, 11)
         go = torch.randn_like(out); gb = torch.randn_like(band)
-        ms = timeit(lambda: ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, 11), iters=10)
         per = 4 * N * F * 4 + 4 * N * E * 4 + 3 * N * 11 * 4     # read g, tmpl; write dx, dtmpl; emb in/out
-        print("attn backward B=%d: %.3f ms  %.0f GB/s" % (B, ms, per * B / ms / 1e6))
+        for fused in (False, True):
+            ms = timeit(lambda: ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, 11, fused=fused), iters=10)
+            print("attn backward B=%d [%s]: %.3f ms  %.0f GB/s" % (B, "fused" if fused else "two-pass", ms,
+                                                                    per * B / ms / 1e6))
 if "polar" in which:
     B, Tn, N = 2048, 5, 450
     sb = synth.make_batch(seed=3, B=B, T=Tn)
