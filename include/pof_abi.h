@@ -397,15 +397,20 @@ int pof_drow_heads(const float *feat, int S, int C, int L, const float *w_cls, c
  * pool routes a gradient to the first maximum of its pair (torch.max_pool1d).
  * dbias_in [C] (may be NULL) = sum of dy over (S, L): the gradient of a per-channel bias
  * added in front of the BatchNorm (the convolution's), from the same pass that writes dy.
- * workspace: pof_bn_lrelu_pool_workspace_bytes(S, C, L) bytes (0 = unsupported shape).
+ * groups >= 1 (S % groups == 0): the sequences form `groups` equal contiguous ranges, each
+ * normalised with its OWN batch statistics -- the five scans of a DR-SPAAM window, which the
+ * reference sends through the trunk one after the other (dr_spaam.py:246-262), in one launch;
+ * save_mean / save_invstd are then [groups][C] and the running statistics receive the groups'
+ * updates in order, as `groups` separate calls would give.
+ * workspace: pof_bn_lrelu_pool_workspace_bytes(S, C, L, groups) bytes (0 = unsupported shape).
  * ---------------------------------------------------------------------- */
-size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L);
-int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const float *gamma,
+size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L, int groups);
+int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, int groups, const float *gamma,
                               const float *beta, float *running_mean, float *running_var,
                               double momentum, double eps, double negative_slope, int pool,
                               float *out, float *save_mean, float *save_invstd, void *workspace,
                               size_t workspace_bytes, pof_stream_t stream);
-int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
+int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L, int groups,
                                const float *gamma, const float *beta, const float *save_mean,
                                const float *save_invstd, double negative_slope, int pool, float *dy,
                                float *dgamma, float *dbeta, float *dbias_in, void *workspace,

@@ -57,9 +57,9 @@ SIGNATURES = {
     "pof_associate_odometry": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),
     "pof_conv3_bn_lrelu": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
-    "pof_bn_lrelu_pool_workspace_bytes": (_sz, [_ll, _i, _i]),
-    "pof_bn_lrelu_pool_forward": (_i, [_p, _ll, _i, _i, _p, _p, _p, _p, _d, _d, _d, _i, _p, _p, _p, _p, _sz, _p]),
-    "pof_bn_lrelu_pool_backward": (_i, [_p, _p, _ll, _i, _i, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _sz, _p]),
+    "pof_bn_lrelu_pool_workspace_bytes": (_sz, [_ll, _i, _i, _i]),
+    "pof_bn_lrelu_pool_forward": (_i, [_p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _d, _d, _i, _p, _p, _p, _p, _sz, _p]),
+    "pof_bn_lrelu_pool_backward": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_conv3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pof_conv3_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "pof_drow_heads": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p]),

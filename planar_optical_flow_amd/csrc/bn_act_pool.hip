@@ -33,7 +33,10 @@ constexpr int kBnSlice = 4 * kBnThreads;      // plane positions per workgroup, 
 
 struct BnGeo {
     long long S;        // sequences
-    long long nchunk;   // sample chunks (grid.x)
+    long long nchunk;   // sample chunks (grid.x) = G * ncg
+    long long Sg, ncg;  // sequences and chunks per statistics group
+    int G;              // statistics groups: `groups` equal contiguous ranges of the sequences, each normalised with
+                        // its own batch statistics (the five scans of a DR-SPAAM window in one launch)
     int C, L, P;        // channels, points per sequence, P = C * L
     int W;              // positions per plane slice (multiple of lcm(L, 4))
     int K;              // samples per chunk
@@ -43,9 +46,9 @@ struct BnGeo {
 int gcd_int(int a, int b) { return b ? gcd_int(b, a % b) : a; }
 
 // K samples per workgroup: enough workgroups to fill the part several times over, few enough partial sums
-bool make_geo(long long S, int C, int L, int wg_target, int kmax, BnGeo *g)
+bool make_geo(long long S, int C, int L, int G, int wg_target, int kmax, BnGeo *g)
 {
-    if (S <= 0 || C <= 0 || L <= 0 || L > 256) return false;
+    if (S <= 0 || C <= 0 || L <= 0 || L > 256 || G < 1 || S % G != 0) return false;
     const long long P = (long long)C * L;
     if (P % 4 != 0 || P > (1ll << 30)) return false;
     const int unit = L / gcd_int(L, 4) * 4;
@@ -53,18 +56,22 @@ bool make_geo(long long S, int C, int L, int wg_target, int kmax, BnGeo *g)
     g->W = kBnSlice / unit * unit;
     g->nslice = (int)((P + g->W - 1) / g->W);
     if (g->nslice > 65535) return false;
-    long long want = wg_target / g->nslice;
+    g->G = G;
+    g->Sg = S / G;
+    long long want = wg_target / g->nslice / G;
     if (want < 1) want = 1;
-    long long K = (S + want - 1) / want;
+    long long K = (g->Sg + want - 1) / want;
     if (K < 1) K = 1;
     if (K > kmax) K = kmax;
     g->K = (int)K;
-    g->nchunk = (S + K - 1) / K;
+    g->ncg = (g->Sg + K - 1) / K;
+    g->nchunk = g->ncg * G;
     return g->nchunk <= 0x7fffffffll;
 }
 
 struct Lane {
     int p0;          // first plane position of the lane
+    int grp;         // statistics group of the workgroup's samples
     bool active;
     long long s0, s1;
 };
@@ -75,8 +82,10 @@ __device__ __forceinline__ Lane lane_of(const BnGeo &g)
     const int off = 4 * threadIdx.x;
     l.p0 = blockIdx.y * g.W + off;
     l.active = off < g.W && l.p0 < g.P;
-    l.s0 = (long long)blockIdx.x * g.K;
-    l.s1 = l.s0 + g.K < g.S ? l.s0 + g.K : g.S;
+    l.grp = (int)(blockIdx.x / g.ncg);
+    const long long chunk = blockIdx.x - l.grp * g.ncg, end = (l.grp + 1) * g.Sg;
+    l.s0 = l.grp * g.Sg + chunk * g.K;
+    l.s1 = l.s0 + g.K < end ? l.s0 + g.K : end;
     return l;
 }
 
@@ -136,38 +145,43 @@ __device__ __forceinline__ double2 block_sum2(double2 v, double2 *s_w)
     return t;
 }
 
-__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(const double2 *__restrict__ partial, long long nchunk,
-                                                                 long long S, int L, const float *gamma,
-                                                                 const float *beta, float *running_mean,
-                                                                 float *running_var, double momentum, double eps,
-                                                                 float *save_mean, float *save_invstd, float *scale,
-                                                                 float *shift)
+__global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(const double2 *__restrict__ partial, BnGeo g,
+                                                                 const float *gamma, const float *beta,
+                                                                 float *running_mean, float *running_var,
+                                                                 double momentum, double eps, float *save_mean,
+                                                                 float *save_invstd, float *scale, float *shift)
 {
     __shared__ double2 s_w[kBnThreads / 64];
     const int c = blockIdx.x;
-    double2 acc = make_double2(0.0, 0.0);
-    for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) {
-        const double2 p = partial[c * nchunk + i];
-        acc.x += p.x; acc.y += p.y;
-    }
-    acc = block_sum2(acc, s_w);
-    if (threadIdx.x == 0) {
-        const double n = (double)S * L;
-        const double mean = acc.x / n;
-        double var = acc.y / n - mean * mean;
-        var = var > 0.0 ? var : 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + eps));
-        const float m = (float)mean;
-        const float sc = gamma[c] * invstd;
-        save_mean[c] = m;
-        save_invstd[c] = invstd;
-        scale[c] = sc;
-        shift[c] = fmaf(-m, sc, beta[c]);
-        if (running_mean) running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
-        if (running_var) {
+    const double n = (double)g.Sg * g.L;
+    // the groups in order: the running statistics see G successive updates, as G separate calls would give
+    float rm = running_mean ? running_mean[c] : 0.0f, rv = running_var ? running_var[c] : 0.0f;
+    for (int grp = 0; grp < g.G; ++grp) {
+        double2 acc = make_double2(0.0, 0.0);
+        const double2 *p = partial + (long long)c * g.nchunk + grp * g.ncg;
+        for (long long i = threadIdx.x; i < g.ncg; i += kBnThreads) { acc.x += p[i].x; acc.y += p[i].y; }
+        acc = block_sum2(acc, s_w);
+        if (threadIdx.x == 0) {
+            const double mean = acc.x / n;
+            double var = acc.y / n - mean * mean;
+            var = var > 0.0 ? var : 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + eps));
+            const float m = (float)mean;
+            const float sc = gamma[c] * invstd;
+            const int o = grp * g.C + c;
+            save_mean[o] = m;
+            save_invstd[o] = invstd;
+            scale[o] = sc;
+            shift[o] = fmaf(-m, sc, beta[c]);
             const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-            running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            rm = (float)((1.0 - momentum) * rm + momentum * mean);
+            rv = (float)((1.0 - momentum) * rv + momentum * unbiased);
         }
+        __syncthreads();      // s_w is reused by the next group
+    }
+    if (threadIdx.x == 0) {
+        if (running_mean) running_mean[c] = rm;
+        if (running_var) running_var[c] = rv;
     }
 }
 
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__res
     float sc[4], sh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int c = (l.p0 + i) / g.L;
+        const int c = l.grp * g.C + (l.p0 + i) / g.L;
         sc[i] = scale[c]; sh[i] = shift[c];
     }
     const float *src = y + l.s0 * g.P + l.p0;
@@ -205,14 +219,14 @@ struct BwdConst { float sc[4], sh[4], mu[4], is[4]; };
 // scale / shift are rebuilt from (gamma, beta, mean, 1/std) with the forward's own operations (bn_finalize_kernel),
 // so that the recomputed u = y * scale + shift has the forward's bits: the pool winner and the activation sign
 // depend on it
-__device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int p0, const float *gamma, const float *beta,
+__device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int grp, int p0, const float *gamma, const float *beta,
                                               const float *mean, const float *invstd)
 {
     BwdConst k;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = (p0 + i) / g.L;
-        k.mu[i] = mean[c]; k.is[i] = invstd[c];
+        k.mu[i] = mean[grp * g.C + c]; k.is[i] = invstd[grp * g.C + c];
         k.sc[i] = gamma[c] * k.is[i];
         k.sh[i] = fmaf(-k.mu[i], k.sc[i], beta[c]);
     }
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *
     const Lane l = lane_of(g);
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (l.active) {
-        const BwdConst k = bwd_const(g, l.p0, gamma, beta, mean, invstd);
+        const BwdConst k = bwd_const(g, l.grp, l.p0, gamma, beta, mean, invstd);
         const int po = POOL ? g.P / 2 : g.P;
         const float *src = y + l.s0 * g.P + l.p0;
         const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
@@ -274,24 +288,29 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *
     channel_reduce(g, a, b, s_a, s_b, partial);
 }
 
-__global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 *__restrict__ partial,
-                                                                  long long nchunk, long long S, int L,
+__global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 *__restrict__ partial, BnGeo g,
                                                                   float *dgamma, float *dbeta, float *k1, float *k2)
 {
     __shared__ double2 s_w[kBnThreads / 64];
     const int c = blockIdx.x;
-    double2 acc = make_double2(0.0, 0.0);
-    for (long long i = threadIdx.x; i < nchunk; i += kBnThreads) {
-        const double2 p = partial[c * nchunk + i];
-        acc.x += p.x; acc.y += p.y;
+    const double n = (double)g.Sg * g.L;
+    double tot_a = 0.0, tot_b = 0.0;
+    for (int grp = 0; grp < g.G; ++grp) {
+        double2 acc = make_double2(0.0, 0.0);
+        const double2 *p = partial + (long long)c * g.nchunk + grp * g.ncg;
+        for (long long i = threadIdx.x; i < g.ncg; i += kBnThreads) { acc.x += p[i].x; acc.y += p[i].y; }
+        acc = block_sum2(acc, s_w);
+        if (threadIdx.x == 0) {
+            k1[grp * g.C + c] = (float)(acc.x / n);
+            k2[grp * g.C + c] = (float)(acc.y / n);
+            tot_a += acc.x;
+            tot_b += acc.y;
+        }
+        __syncthreads();
     }
-    acc = block_sum2(acc, s_w);
     if (threadIdx.x == 0) {
-        const double n = (double)S * L;
-        dbeta[c] = (float)acc.x;
-        dgamma[c] = (float)acc.y;
-        k1[c] = (float)(acc.x / n);
-        k2[c] = (float)(acc.y / n);
+        dbeta[c] = (float)tot_a;
+        dgamma[c] = (float)tot_b;
     }
 }
 
@@ -313,11 +332,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *_
     const Lane l = lane_of(g);
     double acc[4] = {0, 0, 0, 0};
     if (l.active) {
-        const BwdConst k = bwd_const(g, l.p0, gamma, beta, mean, invstd);
+        const BwdConst k = bwd_const(g, l.grp, l.p0, gamma, beta, mean, invstd);
         float m1[4], m2[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int c = (l.p0 + i) / g.L;
+            const int c = l.grp * g.C + (l.p0 + i) / g.L;
             m1[i] = k1[c]; m2[i] = k2[c];
         }
         const int po = POOL ? g.P / 2 : g.P;
@@ -356,7 +375,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_sum_final_kernel(const double2 
     if (threadIdx.x == 0) out[c] = (float)acc.x;
 }
 
-// workspace: double2 partial[C * nchunk_max] | float coef[4 * C]
+// workspace: double2 partial[C * nchunk_max] | float coef[4 * G * C]
 constexpr int kStatsWgs = 4096, kStatsK = 64;      // reductions: few partial sums
 constexpr int kStreamWgs = 8192, kStreamK = 16;  // element-wise passes: short loops, many workgroups
 
@@ -366,19 +385,20 @@ size_t partial_bytes(const BnGeo &g) { return (size_t)g.C * (size_t)g.nchunk * s
 size_t workspace_need(const BnGeo &gs, const BnGeo &ga)
 {
     const size_t p = partial_bytes(gs) > partial_bytes(ga) ? partial_bytes(gs) : partial_bytes(ga);
-    return p + 4 * (size_t)gs.C * sizeof(float);
+    return p + 4 * (size_t)gs.G * gs.C * sizeof(float);
 }
 
 }  // namespace
 
-extern "C" size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L)
+extern "C" size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L, int groups)
 {
     BnGeo gs, ga;
-    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga)) return 0;
+    if (!make_geo(S, C, L, groups, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, groups, kStreamWgs, kStreamK, &ga))
+        return 0;
     return workspace_need(gs, ga);
 }
 
-extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, const float *gamma,
+extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int L, int groups, const float *gamma,
                                          const float *beta, float *running_mean, float *running_var, double momentum,
                                          double eps, double negative_slope, int pool, float *out, float *save_mean,
                                          float *save_invstd, void *workspace, size_t workspace_bytes,
@@ -387,19 +407,19 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
     POF_CLEAR_STALE_ERROR();
     if (!y || !gamma || !beta || !out || !save_mean || !save_invstd || !workspace) return POF_E_BADARG;
     BnGeo gs, ga;
-    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga))
+    if (!make_geo(S, C, L, groups, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, groups, kStreamWgs, kStreamK, &ga))
         return POF_E_SHAPE;
     if (pool && (L & 1)) return POF_E_SHAPE;
     if (!(eps >= 0.0)) return POF_E_BADARG;
     if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
-    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * C;
-    float *scale = coef, *shift = coef + C;
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * groups * C;
+    float *scale = coef, *shift = coef + groups * C;
     hipStream_t st = pof_stream(stream);
     bn_stats_kernel<<<dim3((unsigned)gs.nchunk, gs.nslice), kBnThreads, 0, st>>>(y, gs, partial);
     POF_CHECK_LAUNCH();
-    bn_finalize_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, gamma, beta, running_mean, running_var,
-                                                 momentum, eps, save_mean, save_invstd, scale, shift);
+    bn_finalize_kernel<<<C, kBnThreads, 0, st>>>(partial, gs, gamma, beta, running_mean, running_var, momentum, eps,
+                                                 save_mean, save_invstd, scale, shift);
     POF_CHECK_LAUNCH();
     const dim3 grid((unsigned)ga.nchunk, ga.nslice);
     if (pool) bn_apply_kernel<true><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
@@ -408,7 +428,7 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
     return POF_OK;
 }
 
-extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L,
+extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int C, int L, int groups,
                                           const float *gamma, const float *beta, const float *save_mean,
                                           const float *save_invstd, double negative_slope, int pool, float *dy,
                                           float *dgamma, float *dbeta, float *dbias_in, void *workspace,
@@ -418,20 +438,20 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     if (!y || !dz || !gamma || !beta || !save_mean || !save_invstd || !dy || !dgamma || !dbeta || !workspace)
         return POF_E_BADARG;
     BnGeo gs, ga;
-    if (!make_geo(S, C, L, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, kStreamWgs, kStreamK, &ga))
+    if (!make_geo(S, C, L, groups, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, groups, kStreamWgs, kStreamK, &ga))
         return POF_E_SHAPE;
     if (pool && (L & 1)) return POF_E_SHAPE;
     if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
-    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * C;
-    float *k1 = coef + 2 * C, *k2 = coef + 3 * C;
+    float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * groups * C;
+    float *k1 = coef + 2 * groups * C, *k2 = coef + 3 * groups * C;
     const float slope = (float)negative_slope;
     hipStream_t st = pof_stream(stream);
     const dim3 rgrid((unsigned)gs.nchunk, gs.nslice), dgrid((unsigned)ga.nchunk, ga.nslice);
     if (pool) bn_bwd_reduce_kernel<true><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
     else bn_bwd_reduce_kernel<false><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
     POF_CHECK_LAUNCH();
-    bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs.nchunk, S, L, dgamma, dbeta, k1, k2);
+    bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs, dgamma, dbeta, k1, k2);
     POF_CHECK_LAUNCH();
 #define POF_DGRAD(P_, D_) bn_bwd_dgrad_kernel<P_, D_><<<dgrid, kBnThreads, 0, st>>>( \
         y, dz, ga, gamma, beta, save_mean, save_invstd, k1, k2, slope, dy, partial)

@@ -393,24 +393,28 @@ def conv3_wgrad(x, dy):
     return dw
 
 
-def bn_lrelu_pool_supported(S, C, L, pool=False):
-    """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, L even when pooled)."""
+def bn_lrelu_pool_supported(S, C, L, pool=False, groups=1):
+    """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, L even when pooled,
+    S % groups == 0)."""
     if pool and (L & 1):
         return False
-    return S > 0 and int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L))) > 0
+    return S > 0 and int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L), int(groups))) > 0
 
 
-def _bn_workspace(S, C, L, device):
-    nbytes = int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L)))
+def _bn_workspace(S, C, L, groups, device):
+    nbytes = int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L), int(groups)))
     if nbytes == 0:
-        raise ValueError("bn_lrelu_pool: unsupported shape S=%d C=%d L=%d (needs L <= 256 and C*L %% 4 == 0)" % (S, C, L))
+        raise ValueError("bn_lrelu_pool: unsupported shape S=%d C=%d L=%d groups=%d (needs L <= 256, C*L %% 4 == 0, "
+                         "S %% groups == 0)" % (S, C, L, groups))
     return torch.empty((nbytes + 7) // 8, dtype=torch.float64, device=device), nbytes
 
 
 def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5,
-                          negative_slope=0.1, pool=False):
-    """N2 training tail: y [S,C,L] f32 (convolution output) -> (z [S,C,L or L//2], save_mean [C], save_invstd [C]);
-    z = max_pool1d?(leaky_relu(batch_norm_train(y))).  running_mean / running_var are updated in place."""
+                          negative_slope=0.1, pool=False, groups=1):
+    """N2 training tail: y [S,C,L] f32 (convolution output) -> (z [S,C,L or L//2], save_mean [groups*C],
+    save_invstd [groups*C]); z = max_pool1d?(leaky_relu(batch_norm_train(y))), the batch statistics taken separately
+    over each of `groups` equal contiguous ranges of the sequences.  running_mean / running_var are updated in
+    place (once per group, in order)."""
     y = _dev(y, torch.float32, "y")
     gamma = _dev(gamma, torch.float32, "gamma")
     beta = _dev(beta, torch.float32, "beta")
@@ -420,19 +424,19 @@ def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, m
     for name, t in (("running_mean", running_mean), ("running_var", running_var)):
         if t is not None and (_dev(t, torch.float32, name).numel() != C):
             raise ValueError("%s must have C entries" % name)
-    ws, nbytes = _bn_workspace(S, C, L, y.device)
+    ws, nbytes = _bn_workspace(S, C, L, groups, y.device)
     out = torch.empty((S, C, L // 2 if pool else L), dtype=torch.float32, device=y.device)
-    mean = torch.empty(C, dtype=torch.float32, device=y.device)
-    invstd = torch.empty(C, dtype=torch.float32, device=y.device)
+    mean = torch.empty(groups * C, dtype=torch.float32, device=y.device)
+    invstd = torch.empty(groups * C, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
-        _lib.call("pof_bn_lrelu_pool_forward", _ptr(y), S, C, L, _ptr(gamma), _ptr(beta), _ptr(running_mean),
-                  _ptr(running_var), float(momentum), float(eps), float(negative_slope), int(bool(pool)), _ptr(out),
-                  _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream())
+        _lib.call("pof_bn_lrelu_pool_forward", _ptr(y), S, C, L, int(groups), _ptr(gamma), _ptr(beta),
+                  _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), float(negative_slope),
+                  int(bool(pool)), _ptr(out), _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream())
     return out, mean, invstd
 
 
 def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_slope=0.1, pool=False,
-                           bias_grad=False):
+                           bias_grad=False, groups=1):
     """Backward of bn_lrelu_pool_forward: -> (dy [S,C,L], dgamma [C], dbeta [C]) and, with ``bias_grad``, also
     sum(dy) over (S, L) [C] -- the gradient of the convolution bias in front of the BatchNorm."""
     y = _dev(y, torch.float32, "y")
@@ -440,18 +444,19 @@ def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_
     S, C, L = y.shape
     if tuple(dz.shape) != (S, C, L // 2 if pool else L):
         raise ValueError("dz must be [S, C, %s]" % ("L//2" if pool else "L"))
-    for name, t in (("gamma", gamma), ("beta", beta), ("save_mean", save_mean), ("save_invstd", save_invstd)):
-        if _dev(t, torch.float32, name).numel() != C:
-            raise ValueError("%s must have C entries" % name)
-    ws, nbytes = _bn_workspace(S, C, L, y.device)
+    for name, t, n in (("gamma", gamma, C), ("beta", beta, C), ("save_mean", save_mean, groups * C),
+                       ("save_invstd", save_invstd, groups * C)):
+        if _dev(t, torch.float32, name).numel() != n:
+            raise ValueError("%s must have %d entries" % (name, n))
+    ws, nbytes = _bn_workspace(S, C, L, groups, y.device)
     dy = torch.empty_like(y)
     dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
     dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     dbias = torch.empty(C, dtype=torch.float32, device=y.device) if bias_grad else None
     with torch.cuda.device(y.device):
-        _lib.call("pof_bn_lrelu_pool_backward", _ptr(y), _ptr(dz), S, C, L, _ptr(gamma), _ptr(beta), _ptr(save_mean),
-                  _ptr(save_invstd), float(negative_slope), int(bool(pool)), _ptr(dy), _ptr(dgamma), _ptr(dbeta),
-                  _ptr(dbias), _ptr(ws), nbytes, _stream())
+        _lib.call("pof_bn_lrelu_pool_backward", _ptr(y), _ptr(dz), S, C, L, int(groups), _ptr(gamma), _ptr(beta),
+                  _ptr(save_mean), _ptr(save_invstd), float(negative_slope), int(bool(pool)), _ptr(dy), _ptr(dgamma),
+                  _ptr(dbeta), _ptr(dbias), _ptr(ws), nbytes, _stream())
     return (dy, dgamma, dbeta, dbias) if bias_grad else (dy, dgamma, dbeta)
 
 

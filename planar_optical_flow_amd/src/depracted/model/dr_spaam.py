@@ -207,23 +207,34 @@ class DROW(nn.Module):
         return torch.max_pool1d(out, kernel_size=2) if pool else out
 
     @staticmethod
-    def _run_block_train(x, block, pool, hip_conv=True):
-        """Training on the GPU: convolution forward and data gradient on the HIP implicit-GEMM kernel
-        (``torch_ops.Conv3Train``; the weight gradient stays MIOpen's), the BatchNorm(train) + LeakyReLU
-        [+ max-pool] tail of every unit and its backward pass as the fused HIP passes of ``pof::bn_lrelu_pool``
-        (the framework's own kernels for that tail take 17 ms of a 41 ms step on sequences this short)."""
+    def _unit_routes(unit, hip_conv, S, L, dtype, last, groups=1):
+        """(conv on the HIP kernels?, tail on the fused passes?) for one trunk unit and input shape."""
+        conv, bn = unit[0], unit[1]
+        conv_ok = hip_conv and conv.kernel_size == (3,) and conv.padding == (1,) and conv.stride == (1,) \
+            and conv.dilation == (1,) and conv.groups == 1 and conv.padding_mode == "zeros" \
+            and dtype == torch.float32
+        tail_ok = type(bn) is nn.BatchNorm1d and bn.training and bn.affine and dtype == torch.float32 \
+            and (groups == 1 or bn.momentum is not None) \
+            and ops.bn_lrelu_pool_supported(S, conv.out_channels, L, last, groups)
+        return conv_ok, tail_ok
+
+    @staticmethod
+    def _run_block_train(x, block, pool, hip_conv=True, groups=1):
+        """Training on the GPU: every unit -- convolution forward, data and weight gradient on the HIP MFMA kernels,
+        BatchNorm(train) + LeakyReLU [+ max-pool] and its backward as the fused passes of ``pof::bn_lrelu_pool`` --
+        as one autograd node (``torch_ops.TrunkUnitTrain``).  ``groups`` > 1: x holds that many
+        batches one after the other, each with its own BatchNorm statistics (all units must take the fused
+        route then; ``_grouped_blocks_ok`` checks)."""
         out = x
         for i, unit in enumerate(block):
             conv, bn, act = unit[0], unit[1], unit[2]
             last = pool and i == len(block) - 1
-            conv_ok = hip_conv and conv.kernel_size == (3,) and conv.padding == (1,) and conv.stride == (1,) \
-                and conv.dilation == (1,) and conv.groups == 1 and conv.padding_mode == "zeros" \
-                and out.dtype == torch.float32
-            tail_ok = type(bn) is nn.BatchNorm1d and bn.training and bn.affine and out.dtype == torch.float32 \
-                and ops.bn_lrelu_pool_supported(out.shape[0], conv.out_channels, out.shape[2], last)
+            conv_ok, tail_ok = DROW._unit_routes(unit, hip_conv, out.shape[0], out.shape[2], out.dtype, last, groups)
             if conv_ok and tail_ok:
-                out = torch_ops.trunk_unit_train(out, conv, bn, act.negative_slope, last)
+                out = torch_ops.trunk_unit_train(out, conv, bn, act.negative_slope, last, groups)
                 continue
+            if groups != 1:
+                raise RuntimeError("grouped trunk pass on a unit that cannot take the fused route")
             y = torch_ops.conv3_train(out, conv) if conv_ok else conv(out)
             if tail_ok and y.dtype == torch.float32:
                 out = torch_ops.bn_lrelu_pool_train(y, bn, act.negative_slope, last)
@@ -232,6 +243,19 @@ class DROW(nn.Module):
                 if last:
                     out = torch.max_pool1d(out, kernel_size=2)
         return out
+
+    def _grouped_blocks_ok(self, names, S, L, dtype, groups):
+        """Every unit of the pooled blocks `names` takes the fused route for S sequences of L points in `groups`
+        statistics groups."""
+        hip_conv = getattr(self, "hip_train_conv", True)
+        for name in names:
+            block = getattr(self, name)
+            for i, unit in enumerate(block):
+                last = i == len(block) - 1
+                if not all(self._unit_routes(unit, hip_conv, S, L, dtype, last, groups)):
+                    return False
+            L //= 2
+        return True
 
     @staticmethod
     def _run_block_gemm(x, block, pool):
@@ -307,6 +331,25 @@ class SpatialDROW(DROW):
     def _scan_features(self, x, t):
         return self._forward_cutout(x[:, :, t, :].unsqueeze(dim=2)).squeeze(dim=2)
 
+    def _all_scan_features(self, x):
+        """Training on the GPU: the trunk features of ALL scans of the window in one pass per layer instead of one
+        pass per scan.  The reference sends the scans through blocks 1-2 one after the other (:246-262), i.e. every
+        BatchNorm normalises each scan with that scan's own batch statistics and updates its running statistics
+        once per scan; the convolutions are per-sequence anyway.  Here the scans are stacked scan-major and the fused
+        units run with ``groups = n_scan`` statistics groups -- the same numbers, from 5x larger launches (no
+        partly filled last round of workgroups per scan, one weight-gradient reduction instead of five plus four
+        gradient accumulations per parameter).  Returns the per-scan features, or None when a unit cannot take the
+        fused route (SyncBatchNorm, CPU, autocast, ...): the caller then goes scan by scan."""
+        B, N, T, P = x.shape
+        if not (self.training and x.is_cuda and x.dtype == torch.float32 and T > 1 and self.dropout == 0
+                and getattr(self, "fused_train_tail", True) and getattr(self, "grouped_scans", True)
+                and self._grouped_blocks_ok(("conv_block_1", "conv_block_2"), T * B * N, P, x.dtype, T)):
+            return None
+        out = x.permute(2, 0, 1, 3).reshape(T * B * N, 1, P)                  # scan-major: one group per scan
+        for name in ("conv_block_1", "conv_block_2"):
+            out = self._run_block_train(out, getattr(self, name), True, getattr(self, "hip_train_conv", True), T)
+        return out.view(T, B, N, out.shape[-2], out.shape[-1]).unbind(0)
+
     def forward(self, x, testing=False, fea_template=None):
         if testing:   # streaming inference: one new scan against the running template
             out = self._scan_features(x, 0)
@@ -319,10 +362,12 @@ class SpatialDROW(DROW):
             return pred_cls, pred_reg, out_template, feat_fused
         n_scan = x.shape[2]
         with torch_ops.weight_layout_scope():   # the same trunk weights serve every scan of the window
-            out_template = self._scan_features(x, 0)
+            feats = self._all_scan_features(x)
+            scan = (lambda t: feats[t]) if feats is not None else (lambda t: self._scan_features(x, t))
+            out_template = scan(0)
             for i in range(1, n_scan - 1):
-                out_template, _ = self.gate(self._scan_features(x, i), out_template)
-            out_template, feat_fused = self.gate(self._scan_features(x, n_scan - 1), out_template)
+                out_template, _ = self.gate(scan(i), out_template)
+            out_template, feat_fused = self.gate(scan(n_scan - 1), out_template)
             pred_cls, pred_reg = self._forward_fused_cutout(out_template)
         return pred_cls, pred_reg, feat_fused
 

@@ -17,10 +17,11 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
     pof::conv3_bn_lrelu(Tensor x, Tensor wt, Tensor scale, Tensor shift, bool pool, float negative_slope) -> Tensor
     pof::rotate_flow(Tensor flow, Tensor tab, bool to_canonical) -> Tensor
     pof::bn_lrelu_pool(Tensor y, Tensor gamma, Tensor beta, Tensor(a!)? running_mean, Tensor(b!)? running_var,
-        float momentum, float eps, float negative_slope, bool pool) -> (Tensor z, Tensor mean, Tensor invstd)
+        float momentum, float eps, float negative_slope, bool pool, int groups=1)
+        -> (Tensor z, Tensor mean, Tensor invstd)
     pof::conv3_wgrad(Tensor x, Tensor dy) -> Tensor
     pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
-        float negative_slope, bool pool, bool bias_grad) -> (Tensor, Tensor, Tensor, Tensor)
+        float negative_slope, bool pool, bool bias_grad, int groups=1) -> (Tensor, Tensor, Tensor, Tensor)
 """
 from typing import Optional, Tuple
 
@@ -155,31 +156,32 @@ def _(x, wt, scale, shift, pool, negative_slope):
 @torch.library.custom_op("pof::bn_lrelu_pool", mutates_args=("running_mean", "running_var"), device_types="cuda")
 def bn_lrelu_pool(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
                   running_var: Optional[torch.Tensor], momentum: float, eps: float, negative_slope: float,
-                  pool: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                  pool: bool, groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     z, mean, invstd = ops.bn_lrelu_pool_forward(y.contiguous(), gamma.contiguous(), beta.contiguous(), running_mean,
-                                                running_var, momentum, eps, negative_slope, pool)
+                                                running_var, momentum, eps, negative_slope, pool, groups=groups)
     return z, mean, invstd
 
 
 @bn_lrelu_pool.register_fake
-def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
+def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool, groups=1):
     S, C, L = y.shape
-    return (y.new_empty((S, C, L // 2 if pool else L)), y.new_empty((C,)), y.new_empty((C,)))
+    return (y.new_empty((S, C, L // 2 if pool else L)), y.new_empty((groups * C,)), y.new_empty((groups * C,)))
 
 
 @torch.library.custom_op("pof::bn_lrelu_pool_backward", mutates_args=(), device_types="cuda")
 def bn_lrelu_pool_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                            mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, pool: bool,
-                           bias_grad: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                           bias_grad: bool, groups: int = 1
+                           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     res = ops.bn_lrelu_pool_backward(y, dz.contiguous().float(), gamma.contiguous(), beta.contiguous(), mean, invstd,
-                                     negative_slope, pool, bias_grad=bias_grad)
+                                     negative_slope, pool, bias_grad=bias_grad, groups=groups)
     if bias_grad:
         return res
     return res[0], res[1], res[2], gamma.new_empty((0,))
 
 
 @bn_lrelu_pool_backward.register_fake
-def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool, bias_grad):
+def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool, bias_grad, groups=1):
     return (torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta),
             gamma.new_empty((gamma.shape[0] if bias_grad else 0,)))
 
@@ -205,13 +207,15 @@ class BnLreluPool(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
-def _bn_train_args(bn):
+def _bn_train_args(bn, groups=1):
     """(running_mean, running_var, momentum, eps) of a BatchNorm in training mode, batch counter advanced as the
-    module itself does."""
+    module itself does -- by `groups` when that many batches go through it in one grouped call."""
     momentum = bn.momentum
     if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        bn.num_batches_tracked.add_(groups)
         if momentum is None:    # cumulative moving average
+            if groups != 1:
+                raise ValueError("grouped statistics need a fixed BatchNorm momentum")
             momentum = 1.0 / float(bn.num_batches_tracked)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return rm, rv, float(momentum if momentum is not None else 0.0), float(bn.eps)
@@ -334,15 +338,16 @@ class TrunkUnitTrain(torch.autograd.Function):
     kept for the backward pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool,
+                groups):
         co = weight.shape[0]
         wt, wd = _weight_layouts(weight, ctx.needs_input_grad[0])
         shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
         y = torch.ops.pof.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
         z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
-                                                      negative_slope, pool)
+                                                      negative_slope, pool, groups)
         ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd, wd)
-        ctx.has_bias, ctx.negative_slope, ctx.pool = bias is not None, negative_slope, pool
+        ctx.has_bias, ctx.negative_slope, ctx.pool, ctx.groups = bias is not None, negative_slope, pool, groups
         return z
 
     @staticmethod
@@ -351,21 +356,24 @@ class TrunkUnitTrain(torch.autograd.Function):
         co, ci, _ = weight.shape
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
-                                                                     ctx.negative_slope, ctx.pool, want_db)
+                                                                     ctx.negative_slope, ctx.pool, want_db, ctx.groups)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(x, dy, weight)
-        return dx, dw, (db if want_db else None), dgamma, dbeta, None, None, None, None, None, None
+        return dx, dw, (db if want_db else None), dgamma, dbeta, None, None, None, None, None, None, None
 
 
-def trunk_unit_train(x, conv, bn, negative_slope=0.1, pool=False):
-    """``max_pool1d?(leaky_relu(bn(conv(x))))`` for a trunk unit's modules in training mode (see TrunkUnitTrain)."""
-    rm, rv, momentum, eps = _bn_train_args(bn)
+def trunk_unit_train(x, conv, bn, negative_slope=0.1, pool=False, groups=1):
+    """``max_pool1d?(leaky_relu(bn(conv(x))))`` for a trunk unit's modules in training mode (see TrunkUnitTrain).
+    ``groups`` > 1: x holds that many equally long batches one after the other (the scans of a window); each is
+    normalised with its own batch statistics and the module's running statistics see them in order -- the result
+    of sending the batches through the unit one by one, in one launch per pass."""
+    rm, rv, momentum, eps = _bn_train_args(bn, groups)
     return TrunkUnitTrain.apply(x.contiguous(), conv.weight, conv.bias, bn.weight, bn.bias, rm, rv, momentum, eps,
-                                float(negative_slope), bool(pool))
+                                float(negative_slope), bool(pool), int(groups))
 
 
 # ------------------------------------------------------------------------------------------------- A4

@@ -340,3 +340,67 @@ def test_training_trunk_compiles():
     gscale = max(float(p.grad.abs().max()) for p in ref.parameters() if p.grad is not None)
     for (n, p), q in zip(m.named_parameters(), ref.parameters()):
         assert float((p.grad - q.grad).abs().max()) <= 2e-3 * gscale, n
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("G,Sg,C,L,pool", [(5, 40, 64, 48, True), (3, 17, 128, 12, False), (2, 1, 8, 6, True)])
+def test_bn_lrelu_pool_groups_equal_separate_calls(G, Sg, C, L, pool):
+    """`groups` statistics groups in one launch against G separate calls on the G slices: outputs, saved statistics,
+    running statistics (updated in order) bit-identical; the gradients of the slices too, gamma / beta gradients the
+    sums over the groups."""
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(G * 100 + C)
+    y = torch.randn(G * Sg, C, L, device="cuda", generator=g) * 1.5 + 0.3
+    for k in range(G):
+        y[k * Sg:(k + 1) * Sg] += k * 0.7            # different statistics per group
+    gam = torch.rand(C, device="cuda", generator=g) + 0.5
+    bet = torch.rand(C, device="cuda", generator=g) - 0.5
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    z, mu, istd = ops.bn_lrelu_pool_forward(y, gam, bet, rm, rv, pool=pool, groups=G)
+    rm1, rv1 = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    dz = torch.randn(z.shape, device="cuda", generator=g)
+    dy, dgam, dbet, dsum = ops.bn_lrelu_pool_backward(y, dz, gam, bet, mu, istd, pool=pool, bias_grad=True, groups=G)
+    acc_g, acc_b, acc_s = (torch.zeros(C, device="cuda", dtype=torch.float64) for _ in range(3))
+    for k in range(G):
+        sl = slice(k * Sg, (k + 1) * Sg)
+        zk, muk, ik = ops.bn_lrelu_pool_forward(y[sl].contiguous(), gam, bet, rm1, rv1, pool=pool)
+        assert torch.equal(zk, z[sl]) and torch.equal(muk, mu[k * C:(k + 1) * C]) and torch.equal(ik, istd[k * C:(k + 1) * C])
+        dyk, dgk, dbk, dsk = ops.bn_lrelu_pool_backward(y[sl].contiguous(), dz[sl].contiguous(), gam, bet, muk, ik,
+                                                        pool=pool, bias_grad=True)
+        assert torch.equal(dyk, dy[sl])
+        acc_g += dgk.double(); acc_b += dbk.double(); acc_s += dsk.double()
+    assert torch.equal(rm, rm1) and torch.equal(rv, rv1)
+    for got, want in ((dgam, acc_g), (dbet, acc_b), (dsum, acc_s)):
+        assert float((got.double() - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+def test_spatial_drow_grouped_scans_equal_scan_by_scan():
+    """SpatialDROW training step with all scans of the window stacked through blocks 1-2 (statistics groups)
+    against the scan-by-scan pass of the same fused units and against the plain torch modules: predictions,
+    every parameter gradient, running statistics and batch counters."""
+    from planar_optical_flow_amd.src.depracted.model.dr_spaam import SpatialDROW
+    torch.manual_seed(12)
+    kw = dict(num_scans=3, num_pts=48, alpha=0.5, window_size=7, pedestrian_only=True)
+    models = [SpatialDROW(**kw).cuda().train() for _ in range(3)]
+    for m in models[1:]:
+        m.load_state_dict(models[0].state_dict())
+    models[1].grouped_scans = False
+    models[2].fused_train_tail = False
+    x = torch.rand(2, 50, 3, 48, device="cuda") * 3
+    outs = []
+    for m in models:
+        cls, reg, sim = m(x)
+        (cls.square().mean() + reg.square().mean() + sim.square().mean() * 1e-3).backward()
+        outs.append((cls.detach(), reg.detach()))
+    assert models[0]._grouped_blocks_ok(("conv_block_1", "conv_block_2"), 3 * 2 * 50, 48, torch.float32, 3)
+    for k, tol in ((1, 1e-5), (2, 1e-3)):
+        assert torch.allclose(outs[0][0], outs[k][0], rtol=tol, atol=tol * 0.1)
+        assert torch.allclose(outs[0][1], outs[k][1], rtol=tol, atol=tol * 0.1)
+        gscale = max(float(p.grad.abs().max()) for p in models[k].parameters() if p.grad is not None)
+        for (n, p), q in zip(models[0].named_parameters(), models[k].parameters()):
+            assert (p.grad is None) == (q.grad is None), n
+            if p.grad is not None:
+                assert float((p.grad - q.grad).abs().max()) <= (2e-4 if k == 1 else 2e-3) * gscale, (k, n)
+        for (n, p), q in zip(models[0].named_buffers(), models[k].buffers()):
+            assert torch.allclose(p.double(), q.double(), rtol=1e-4, atol=1e-5), (k, n)
