@@ -341,6 +341,13 @@ class SpatialDROW(DROW):
         gradient accumulations per parameter).  Returns the per-scan features, or None when a unit cannot take the
         fused route (SyncBatchNorm, CPU, autocast, ...): the caller then goes scan by scan."""
         B, N, T, P = x.shape
+        if not self.training and x.is_cuda and T > 1 and getattr(self, "_fused", None) is not None \
+                and not torch.is_grad_enabled() and getattr(self, "grouped_scans", True):
+            # inference on the folded trunk: nothing couples the sequences, the scans simply share the launches
+            out = x.permute(2, 0, 1, 3).reshape(T * B * N, 1, P)
+            for name in ("conv_block_1", "conv_block_2"):
+                out = self._run_block(out, name, pool=True)
+            return out.view(T, B, N, out.shape[-2], out.shape[-1]).unbind(0)
         if not (self.training and x.is_cuda and x.dtype == torch.float32 and T > 1 and self.dropout == 0
                 and getattr(self, "fused_train_tail", True) and getattr(self, "grouped_scans", True)
                 and self._grouped_blocks_ok(("conv_block_1", "conv_block_2"), T * B * N, P, x.dtype, T)):
