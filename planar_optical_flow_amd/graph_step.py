@@ -72,6 +72,8 @@ class GraphedTrainStep:
         # parameters, buffers and optimiser state are put back afterwards (in place: the graphs hold their addresses)
         saved = [t.detach().clone() for t in list(model.parameters()) + list(model.buffers())] if restore else None
         self._capture(warmup)
+        self._tracked = [p for p in model.parameters() if p.requires_grad]
+        self._addresses = [(p.data_ptr(), p.grad.data_ptr() if p.grad is not None else 0) for p in self._tracked]
         if restore:
             with torch.no_grad():
                 for t, v in zip(list(model.parameters()) + list(model.buffers()), saved):
@@ -132,7 +134,18 @@ class GraphedTrainStep:
                 self._update()
             self._graphs = [g1, g2]
 
+    def _check_addresses(self):
+        """The graph holds raw addresses of the parameters and of their gradient buffers: a caller that frees them
+        (``zero_grad(set_to_none=True)``, ``p.grad = None``, ``model.to(...)``, ``load_state_dict(assign=True)``)
+        would have the replay write into memory that is no longer theirs.  Refuse instead."""
+        for p, (pa, ga) in zip(self._tracked, self._addresses):
+            if p.data_ptr() != pa or (p.grad.data_ptr() if p.grad is not None else 0) != ga:
+                raise RuntimeError("GraphedTrainStep: a parameter or gradient buffer moved since the capture (gradients "
+                                   "set to None?) -- keep them allocated (zero_grad(set_to_none=False)) or build a new "
+                                   "GraphedTrainStep")
+
     def step(self, batch):
+        self._check_addresses()
         for k in self.keys:
             src = batch[k]
             self.static[k].copy_(src if torch.is_tensor(src) else torch.as_tensor(src), non_blocking=True)

@@ -128,3 +128,20 @@ def test_trainer_graph_step_matches_eager_trainer(tmp_path):
         assert tr.train(model, loader) == 0
         out.append(model)
     _assert_same_training_state(*out)
+
+
+@pytest.mark.gpu
+def test_graphed_step_refuses_freed_gradient_buffers():
+    """The graph owns raw addresses: after zero_grad(set_to_none=True) a replay would write into freed memory."""
+    from planar_optical_flow_amd.graph_step import GraphedTrainStep
+    from src.pipeline.optim import Optim
+    model = _box_model(7).cuda().train()
+    opt = Optim(model, _SCHED)
+    batch = {"input": torch.randn(16, 64, 3, device="cuda"), "target": torch.randn(16, 3, device="cuda")}
+    step = GraphedTrainStep(model, opt.make_capturable(), batch)
+    step(batch)
+    opt.zero_grad(set_to_none=False)
+    step(batch)                                   # buffers kept: fine
+    opt.zero_grad()                               # default: gradients set to None
+    with pytest.raises(RuntimeError, match="moved since the capture"):
+        step(batch)
