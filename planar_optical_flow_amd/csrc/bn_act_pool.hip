@@ -69,6 +69,22 @@ bool make_geo(long long S, int C, int L, int G, int wg_target, int kmax, BnGeo *
     return g->nchunk <= 0x7fffffffll;
 }
 
+// Row loads keep the default cache policy -- the apply pass re-reads what the statistics pass just read, part of it still
+// in the Infinity Cache (non-temporal loads: 0.125 -> 0.150 ms on the forward of [18000 x 64 x 56]); the outputs are
+// written once and read by another kernel much later: non-temporal stores (4.7 -> 6.1 TB/s on the same pass).
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ float2 ld2(const float *p) { return *reinterpret_cast<const float2 *>(p); }
+__device__ __forceinline__ void st4(float *p, float a, float b, float c, float d)
+{
+    using F4 = float __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(F4{a, b, c, d}, reinterpret_cast<F4 *>(p));
+}
+__device__ __forceinline__ void st2(float *p, float a, float b)
+{
+    using F2 = float __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(F2{a, b}, reinterpret_cast<F2 *>(p));
+}
+
 struct Lane {
     int p0;          // first plane position of the lane
     int grp;         // statistics group of the workgroup's samples
@@ -125,7 +141,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_stats_kernel(const float *__res
         const float *src = y + l.s0 * g.P + l.p0;
 #pragma unroll 4
         for (long long s = l.s0; s < l.s1; ++s, src += g.P) {
-            const float4 v = *reinterpret_cast<const float4 *>(src);
+            const float4 v = ld4(src);
             const double d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a[i] += d[i]; b[i] = fma(d[i], d[i], b[i]); }
@@ -206,11 +222,11 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__res
     float *dst = out + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
 #pragma unroll 4
     for (long long s = l.s0; s < l.s1; ++s, src += g.P, dst += po) {
-        const float4 v = *reinterpret_cast<const float4 *>(src);
+        const float4 v = ld4(src);
         const float z0 = lrelu(fmaf(v.x, sc[0], sh[0]), slope), z1 = lrelu(fmaf(v.y, sc[1], sh[1]), slope);
         const float z2 = lrelu(fmaf(v.z, sc[2], sh[2]), slope), z3 = lrelu(fmaf(v.w, sc[3], sh[3]), slope);
-        if (POOL) *reinterpret_cast<float2 *>(dst) = make_float2(z0 >= z1 ? z0 : z1, z2 >= z3 ? z2 : z3);
-        else *reinterpret_cast<float4 *>(dst) = make_float4(z0, z1, z2, z3);
+        if (POOL) st2(dst, z0 >= z1 ? z0 : z1, z2 >= z3 ? z2 : z3);
+        else st4(dst, z0, z1, z2, z3);
     }
 }
 
@@ -238,7 +254,7 @@ template <bool POOL>
 __device__ __forceinline__ void grad_u(const float *src, const float *gsrc, const BwdConst &k, float slope,
                                        float (&du)[4], float (&xh)[4])
 {
-    const float4 v4 = *reinterpret_cast<const float4 *>(src);
+    const float4 v4 = ld4(src);
     const float v[4] = {v4.x, v4.y, v4.z, v4.w};
     float u[4], gz[4];
 #pragma unroll
@@ -248,12 +264,12 @@ __device__ __forceinline__ void grad_u(const float *src, const float *gsrc, cons
     }
     if (POOL) {
         // the pair's winner takes the gradient; max_pool1d keeps the FIRST maximum on a tie
-        const float2 d = *reinterpret_cast<const float2 *>(gsrc);
+        const float2 d = ld2(gsrc);
         const bool f0 = lrelu(u[0], slope) >= lrelu(u[1], slope), f1 = lrelu(u[2], slope) >= lrelu(u[3], slope);
         gz[0] = f0 ? d.x : 0.0f; gz[1] = f0 ? 0.0f : d.x;
         gz[2] = f1 ? d.y : 0.0f; gz[3] = f1 ? 0.0f : d.y;
     } else {
-        const float4 d = *reinterpret_cast<const float4 *>(gsrc);
+        const float4 d = ld4(gsrc);
         gz[0] = d.x; gz[1] = d.y; gz[2] = d.z; gz[3] = d.w;
     }
 #pragma unroll
@@ -353,7 +369,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *_
                 r[i] = k.sc[i] * ((du[i] - m1[i]) - xh[i] * m2[i]);
                 if (DSUM) part[i] += r[i];
             }
-            *reinterpret_cast<float4 *>(dst) = make_float4(r[0], r[1], r[2], r[3]);
+            st4(dst, r[0], r[1], r[2], r[3]);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = (double)part[i];
