@@ -362,6 +362,104 @@ __global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_kernel(const flo
     }
 }
 
+// Backward for n <= 64 (the Prototype's feature maps: n = 57): the whole row of a channel is ONE wave-wide register
+// (lane = position), so the band contraction needs no matrix unit and no operand staging:
+//     d_f1[c][a] = sum_d G[a][a + d] * f2[c][a + d]          d_f2[c][b] = sum_d G[b + d][b] * f1[c][b + d]
+// with |d| <= HB: a lane keeps its 2 * (2 HB + 1) band weights in registers for the whole sample (the row of G
+// through a, the column through b), a channel costs two coalesced 256-byte row loads, 2 (W - 1) wave-wide DPP
+// shifts, 2 W FMAs and two coalesced row stores.  The MFMA form above pads the <= 44-position contraction window to 64 and multiplies
+// mostly structural zeros of the band (13-15 non-zeros per 44): 256 MFMAs + 3900 vector instructions per wave
+// against ~4500 vector instructions here and no matrix work (profiles/r2_corr_bwd_pmc.txt).
+// Phase 1 (the band image G in LDS) is the same gather as in band_corr_bwd_kernel.
+constexpr int kBwdSmallMaxW = 19;       // 2 * HB + 1 <= 19: HB = max_disp + 2 * (K / 2) <= 9
+
+template <int K, int HB>
+__global__ __launch_bounds__(64 * kBwdWaves) void band_corr_bwd_small_kernel(const float *f1, const float *f2,
+                                                                            const float *g_out, float *d_f1,
+                                                                            float *d_f2, int C, int n, int D)
+{
+    constexpr int HK = K / 2, W = 2 * HB + 1;
+    extern __shared__ float s_g[];               // [n][W]: G[a][a - HB + s], then [D][n]: the output gradient
+    const int MD = D / 2;                        // HB == MD + 2 * HK (the launcher picks the instantiation)
+    const int b = blockIdx.x;
+    float *go = s_g + n * W;
+    for (int e = threadIdx.x; e < D * n; e += 64 * kBwdWaves) go[e] = g_out[(long long)b * D * n + e];
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * W; e += 64 * kBwdWaves) {
+        const int a = e / W, s = e - a * W;
+        const int bb = a - HB + s;
+        float acc = 0.0f;
+        if (bb >= 0 && bb < n) {
+            for (int k = 0; k < K; ++k) {
+                int i_lo = a - k + HK, i_hi = i_lo;
+                if (a == 0) i_lo = 0;
+                if (a == n - 1) i_hi = n - 1;
+                i_lo = max(i_lo, 0);
+                i_hi = min(i_hi, n - 1);
+                for (int i = i_lo; i <= i_hi; ++i) {
+                    if (min(max(i + k - HK, 0), n - 1) != a) continue;
+                    for (int d = 0; d < D; ++d) {
+                        const int j = min(max(i + d - MD, 0), n - 1);
+                        if (min(max(j + k - HK, 0), n - 1) == bb) acc += go[d * n + i];
+                    }
+                }
+            }
+        }
+        s_g[e] = acc;
+    }
+    __syncthreads();
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool live = lane < n;
+    // band weights of this lane's position p = lane, slot s <-> offset d = s - HB:
+    //   wr[s] = G[p][p + d]  (row through p)       -> d_f1
+    //   wc[s] = G[p + d][p]  (column through p)    -> d_f2;   G[a][b] lives at s_g[a * W + b - a + HB]
+    float wr[W], wc[W];                         // slot HB + d <-> offset d
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+        const int d = s - HB, q = lane + d;
+        const bool ok = live && q >= 0 && q < n;
+        wr[s] = ok ? s_g[lane * W + (HB + d)] : 0.0f;
+        wc[s] = ok ? s_g[q * W + (HB - d)] : 0.0f;
+    }
+    // neighbours through the wave-wide DPP shifts of GFX9 (v_mov_b32_dpp wave_shl:1 / wave_shr:1: lane i reads lane
+    // i + 1 / i - 1 across the row boundaries, the end lane reads 0 with bound_ctrl; tools/ubench/dpp_wave_shift.hip):
+    // vector-pipe moves, no LDS traffic -- the ds_bpermute form of this loop is LDS-issue bound (0.46 ms)
+    auto shl1 = [](float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+    };
+    auto shr1 = [](float v) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+    };
+    const int lc = live ? lane : n - 1;          // dead lanes load a valid address and are zeroed after the load
+    const float *r1 = f1 + (long long)b * C * n + lc, *r2 = f2 + (long long)b * C * n + lc;
+    float *o1 = d_f1 + (long long)b * C * n + lane, *o2 = d_f2 + (long long)b * C * n + lane;
+    // next channel's rows are in flight while this one's shifts and FMAs run
+    float nv1 = 0.0f, nv2 = 0.0f;
+    if (wave < C) { nv1 = r1[(long long)wave * n]; nv2 = r2[(long long)wave * n]; }
+    for (int c = wave; c < C; c += kBwdWaves) {
+        const float v1 = live ? nv1 : 0.0f, v2 = live ? nv2 : 0.0f;
+        const int cn = c + kBwdWaves < C ? c + kBwdWaves : c;
+        nv1 = r1[(long long)cn * n];
+        nv2 = r2[(long long)cn * n];
+        float a1 = wr[HB] * v2, a2 = wc[HB] * v1;
+        float p1 = v1, p2 = v2, m1 = v1, m2 = v2;       // values of lane + d / lane - d
+#pragma unroll
+        for (int d = 1; d <= HB; ++d) {
+            p1 = shl1(p1); p2 = shl1(p2);
+            m1 = shr1(m1); m2 = shr1(m2);
+            a1 = fmaf(wr[HB + d], p2, a1);
+            a1 = fmaf(wr[HB - d], m2, a1);
+            a2 = fmaf(wc[HB + d], p1, a2);
+            a2 = fmaf(wc[HB - d], m1, a2);
+        }
+        if (live) {     // ordinary stores: the 228-byte rows are partial lines that L2 merges (non-temporal: 0.255 -> 0.285 ms)
+            o1[(long long)c * n] = a1;
+            o2[(long long)c * n] = a2;
+        }
+    }
+}
+
 template <int K, typename T>
 void launch_k(const T *f1, const T *f2, float *out, int B, int C, int n, int D, hipStream_t s)
 {
@@ -437,6 +535,23 @@ extern "C" int pof_band_correlation_backward(const float *feat1, const float *fe
             return POF_E_LAUNCH;
     }
     hipStream_t s = pof_stream(stream);
+    if (n <= 64 && W <= kBwdSmallMaxW) {        // one wave holds a whole row: the shuffle form, one instantiation per band width
+        const int HB = W / 2;
+#define POF_BWD_SMALL(K_, HB_) band_corr_bwd_small_kernel<K_, HB_><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D)
+#define POF_BWD_SMALL_K(K_)                                                                   \
+        switch (HB) {                                                                        \
+            case 0: POF_BWD_SMALL(K_, 0); break; case 1: POF_BWD_SMALL(K_, 1); break;        \
+            case 2: POF_BWD_SMALL(K_, 2); break; case 3: POF_BWD_SMALL(K_, 3); break;        \
+            case 4: POF_BWD_SMALL(K_, 4); break; case 5: POF_BWD_SMALL(K_, 5); break;        \
+            case 6: POF_BWD_SMALL(K_, 6); break; case 7: POF_BWD_SMALL(K_, 7); break;        \
+            case 8: POF_BWD_SMALL(K_, 8); break; default: POF_BWD_SMALL(K_, 9); break;       \
+        }
+        if (kernel_size == 1) { POF_BWD_SMALL_K(1) } else if (kernel_size == 3) { POF_BWD_SMALL_K(3) } else { POF_BWD_SMALL_K(5) }
+#undef POF_BWD_SMALL_K
+#undef POF_BWD_SMALL
+        POF_CHECK_LAUNCH();
+        return POF_OK;
+    }
     switch (kernel_size) {
         case 1: band_corr_bwd_kernel<1><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D); break;
         case 3: band_corr_bwd_kernel<3><<<B, 64 * kBwdWaves, lds, s>>>(feat1, feat2, g_out, d_feat1, d_feat2, C, n, D); break;
