@@ -67,3 +67,19 @@ __device__ __forceinline__ float wave_max_f32(float v)
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
 }
+
+// Sum over the 64 lanes on the vector pipe only (no LDS-pipe shuffles): four row_shr adds inside each row of 16
+// lanes, then row_bcast15 / row_bcast31 carry the row totals upwards.  The total is valid in LANE 63 only.
+__device__ __forceinline__ float wave_sum_to_lane63_f32(float v)
+{
+#define POF_DPP_ADD(ctrl, rmask, bctl) \
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xF, bctl))
+    POF_DPP_ADD(0x111, 0xF, true);    // row_shr:1
+    POF_DPP_ADD(0x112, 0xF, true);    // row_shr:2
+    POF_DPP_ADD(0x114, 0xF, true);    // row_shr:4
+    POF_DPP_ADD(0x118, 0xF, true);    // row_shr:8   -> lane 15 of every row holds the row's sum
+    POF_DPP_ADD(0x142, 0xA, false);   // row_bcast15 into rows 1 and 3
+    POF_DPP_ADD(0x143, 0xC, false);   // row_bcast31 into rows 2 and 3 -> lane 63 holds the wave's sum
+#undef POF_DPP_ADD
+    return v;
+}

@@ -523,7 +523,7 @@ namespace {
 // The two large passes of the backward both read the output gradient g: the transposed merge (d tmpl, d x) and the
 // band product dp[i][k] = <g[i], tmpl[i-hw+k]>.  Here they are ONE walk down the points: a lane owns one 16-byte
 // column of the rows and keeps two W-deep register rings, of g rows (for d tmpl, as the transposed merge does) and
-// of tmpl rows; at point i the W dot products of its 4 columns are summed over the wave's 64 lanes and lane 0
+// of tmpl rows; at point i the W dot products of its 4 columns are summed over the wave's 64 lanes (DPP adds) and lane 63
 // writes them to partial[column block][b][i][k].  g, tmpl are read once, d tmpl, d x written once: the
 // algorithmic 4 * N * F * 4 bytes (the two-pass form reads g twice and tmpl twice).  A small finishing pass sums
 // the column blocks in a fixed order (deterministic, no atomics) and runs the softmax backward of each row.
@@ -590,8 +590,8 @@ __global__ __launch_bounds__(128) void attn_bwd_fused_kernel(const float4 *__res
                                                         one_minus_alpha * acc.z, one_minus_alpha * acc.w));
                     }
 #pragma unroll
-                    for (int k = 0; k < W; ++k) dp[k] = wave_sum_f32(dp[k]);
-                    if (lane == 0) {
+                    for (int k = 0; k < W; ++k) dp[k] = wave_sum_to_lane63_f32(dp[k]);   // vector pipe, not 66 ds_bpermute
+                    if (lane == 63) {
 #pragma unroll
                         for (int k = 0; k < W; ++k) part[(long long)i * W + k] = dp[k];
                     }
