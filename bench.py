@@ -184,11 +184,34 @@ def launch_ranks(a):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].stdout.read().decode()
+    # rank 0's stdout is drained by a thread; the parent watches all ranks: when one of them dies, the others would
+    # sit in the rendezvous or in the next collective until its timeout -- they are stopped (exactly these PIDs) instead
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    failed = False
+    while True:
+        rcs = [p.poll() for p in procs]
+        if any(rc not in (None, 0) for rc in rcs):
+            failed = True
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        if all(rc is not None for rc in rcs):
+            break
+        time.sleep(0.2)
+    reader.join(timeout=10)
     rcs = [p.wait() for p in procs]
-    sys.stdout.write(out0)
+    sys.stdout.write(b"".join(chunks).decode())
     sys.stdout.flush()
-    if any(rcs):
+    if failed or any(rcs):
         sys.stderr.write("bench.py: rank exit codes %s\n" % rcs)
         return 1
     return 0

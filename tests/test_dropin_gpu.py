@@ -1170,3 +1170,23 @@ def test_eval_person_flow_loop(tmp_path):
             np.testing.assert_allclose(res["pred_flow"][k], u.canonical_to_global_flow(flow[i].cpu().numpy(), phi), atol=1e-6)
             k += 1
     assert sum(len(d) for d in res["dets_xy"]) > 0
+
+
+@pytest.mark.gpu
+def test_bench_launcher_stops_the_other_ranks_when_one_dies():
+    """A rank that cannot start (here: LOCAL_RANK 1 on a one-GPU box, no shared-GPU hook) must not leave the others
+    waiting in the rendezvous: the launcher stops them and fails within seconds, not after a collective timeout."""
+    import subprocess, sys, time
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "POF_BENCH_SHARE_GPU")}
+    env["POF_BENCH_BACKEND"] = "gloo"
+    import torch
+    if torch.cuda.device_count() > 1:
+        pytest.skip("needs a one-GPU box")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "2",
+                        "--repeats", "1", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode != 0
+    assert "rank exit codes" in r.stderr
+    assert time.time() - t0 < 120
