@@ -207,9 +207,12 @@ class BnLreluPool(torch.autograd.Function):
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
 
-def _bn_train_args(bn, groups=1):
+def _bn_train_args(bn, groups=1, shape=None):
     """(running_mean, running_var, momentum, eps) of a BatchNorm in training mode, batch counter advanced as the
-    module itself does -- by `groups` when that many batches go through it in one grouped call."""
+    module itself does -- by `groups` when that many batches go through it in one grouped call.  `shape` = the
+    [S, C, L] of the input: one value per channel and group is refused as torch.nn.functional.batch_norm does."""
+    if shape is not None and (shape[0] // groups) * shape[2] <= 1:
+        raise ValueError("Expected more than 1 value per channel when training, got input size %s" % (tuple(shape),))
     momentum = bn.momentum
     if bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(groups)
@@ -225,7 +228,7 @@ def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
     """Training-mode tail of a trunk unit on the fused kernels: z = max_pool1d?(leaky_relu(bn(y))) for a
     ``torch.nn.BatchNorm1d`` in training mode, with its running statistics and batch counter updated as the
     module itself would."""
-    rm, rv, momentum, eps = _bn_train_args(bn)
+    rm, rv, momentum, eps = _bn_train_args(bn, 1, y.shape)
     return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, momentum, eps, float(negative_slope), bool(pool))
 
 
@@ -371,7 +374,7 @@ def trunk_unit_train(x, conv, bn, negative_slope=0.1, pool=False, groups=1):
     ``groups`` > 1: x holds that many equally long batches one after the other (the scans of a window); each is
     normalised with its own batch statistics and the module's running statistics see them in order -- the result
     of sending the batches through the unit one by one, in one launch per pass."""
-    rm, rv, momentum, eps = _bn_train_args(bn, groups)
+    rm, rv, momentum, eps = _bn_train_args(bn, groups, (x.shape[0], conv.out_channels, x.shape[2]))
     return TrunkUnitTrain.apply(x.contiguous(), conv.weight, conv.bias, bn.weight, bn.bias, rm, rv, momentum, eps,
                                 float(negative_slope), bool(pool), int(groups))
 

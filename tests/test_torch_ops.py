@@ -404,3 +404,14 @@ def test_spatial_drow_grouped_scans_equal_scan_by_scan():
                 assert float((p.grad - q.grad).abs().max()) <= (2e-4 if k == 1 else 2e-3) * gscale, (k, n)
         for (n, p), q in zip(models[0].named_buffers(), models[k].buffers()):
             assert torch.allclose(p.double(), q.double(), rtol=1e-4, atol=1e-5), (k, n)
+
+
+@pytest.mark.gpu
+def test_fused_tail_refuses_one_value_per_channel_like_torch():
+    from planar_optical_flow_amd import torch_ops
+    bn = torch.nn.BatchNorm1d(8).cuda().train()
+    y = torch.randn(1, 8, 1, device="cuda")
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        bn(y)
+    with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
+        torch_ops.bn_lrelu_pool_train(y, bn, 0.1, False)
