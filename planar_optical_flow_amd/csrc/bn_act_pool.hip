@@ -1,10 +1,10 @@
 // N2, training side: the BatchNorm1d(train) + LeakyReLU [+ max_pool1d(2)] tail of every trunk unit
 // (src/depracted/model/dr_spaam.py:8-19 `_conv`, :86-92 `_conv_and_pool`), forward and backward.
 //
-// The convolution itself stays library work in training (MIOpen's training solvers are good on these shapes);
-// what costs the time around it is the element-wise tail: at the reference's batch (8 scans x 450 cutouts x 5
-// scans = 18 000 sequences of 48 points) the framework's BatchNorm / LeakyReLU / max-pool kernels and their
-// backward passes take 17 ms of a 41 ms step (profiles/r2_train_step_kernel_stats.txt) -- sequences of 6..48
+// The convolution passes of a training step run on conv3_kernel / conv3_wgrad_kernel (conv_trunk.hip,
+// conv_wgrad.hip); what costs as much around them in the framework's own form is the element-wise tail: at the
+// reference's batch (8 scans x 450 cutouts x 5 scans = 18 000 sequences of 48 points) the framework's BatchNorm /
+// LeakyReLU / max-pool kernels and their backward passes take 17 ms of a 41 ms step (profiles/r2_train_step_kernel_stats.txt) -- sequences of 6..48
 // points are a poor fit for kernels written for image planes.  Here the tail is four streaming passes:
 //
 //   forward   bn_stats      read y                 -> per-(chunk, channel) sum / sum of squares (float64)

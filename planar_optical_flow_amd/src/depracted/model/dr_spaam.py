@@ -92,7 +92,8 @@ class _SpatialAttention(nn.Module):
 # DROW / SpatialDROW / FlowDROW_pretrained (reference :8-19, :41-121, :220-322).
 # Same sub-module names, construction order and initialisation as the reference, so a
 # reference checkpoint loads with load_state_dict and a seeded construction reproduces the
-# reference's weights.  The conv trunks stay dense MIOpen work; the temporal gate is the
+# reference's weights.  The conv trunks run on the HIP MFMA kernels (inference: fuse_for_inference();
+# training: torch_ops.TrunkUnitTrain); the temporal gate is the
 # HIP attention above.
 # ---------------------------------------------------------------------------------------
 def _conv(in_channel, out_channel, kernel_size, padding):
@@ -142,7 +143,7 @@ class DROW(nn.Module):
         """Fold every conv3 + BatchNorm (running statistics) + bias of the four trunk blocks into
         (transposed weight, scale, shift) triples for ``pof_conv3_bn_lrelu``.  Call after loading a
         checkpoint and after ``.cuda()``; eval-mode forwards then run the trunk as float32-MFMA
-        implicit GEMMs instead of MIOpen convolutions.  Training mode always uses the torch modules."""
+        implicit GEMMs instead of MIOpen convolutions.  (Training mode has its own HIP route, _run_block_train.)"""
         self._fused = None
         if not enable:
             if getattr(self, "gate", None) is not None:
@@ -176,8 +177,8 @@ class DROW(nn.Module):
         """One trunk block; pooled blocks pool after their last layer.  Three routes:
         eval + fuse_for_inference(): the HIP conv kernels (17 ms per B = 32 forward); eval without it on
         the GPU: the channels-last GEMM form below (39 ms; MIOpen's inference path takes 234 ms on these
-        shapes); training on the GPU: MIOpen convolutions + the fused BatchNorm/LeakyReLU/pool tail
-        (_run_block_train); CPU: the plain torch modules."""
+        shapes); training on the GPU: every unit as one autograd node on the HIP kernels (_run_block_train);
+        CPU: the plain torch modules."""
         fused = getattr(self, "_fused", None)
         if fused is not None and not self.training and x.is_cuda and not torch.is_grad_enabled():
             x = x.contiguous().float()
