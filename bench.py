@@ -422,9 +422,19 @@ def main():
         ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
 
-    box = None if (a.no_extra or a.no_train) else bench_box_head(dev, world, rank, backend, barrier)      # all ranks: it holds collectives
-    det_train = None if (a.no_extra or a.no_model or a.no_train) else bench_detector_train(ops, synth, tab, dev, world, rank,
-                                                                             backend, barrier)
+    # the training rows run on all ranks (they hold collectives).  They are extras: an error in one of them (the
+    # same on every rank) is reported in its place instead of costing the line its headline measurement
+    def guarded(fn, *args):
+        try:
+            return fn(*args)
+        except Exception as e:  # noqa: BLE001
+            import traceback
+            sys.stderr.write("bench.py: %s failed on rank %d:\n%s\n" % (fn.__name__, rank, traceback.format_exc()))
+            return {"error": "%s: %s" % (type(e).__name__, e)}
+
+    box = None if (a.no_extra or a.no_train) else guarded(bench_box_head, dev, world, rank, backend, barrier)
+    det_train = None if (a.no_extra or a.no_model or a.no_train) else guarded(bench_detector_train, ops, synth, tab, dev,
+                                                                             world, rank, backend, barrier)
 
     result = None
     if rank == 0:
