@@ -7,7 +7,7 @@ import torch
 from planar_optical_flow_amd import torch_ops  # noqa: F401  (registers torch.ops.pof.*)
 
 OPS = ("band_correlation", "band_correlation_backward", "spatial_attention", "spatial_attention_backward", "cutout",
-       "conv3_bn_lrelu", "rotate_flow")
+       "conv3_bn_lrelu", "rotate_flow", "bn_lrelu_pool", "bn_lrelu_pool_backward", "conv3_wgrad")
 
 
 def test_ops_are_registered_with_schemas():
@@ -16,6 +16,21 @@ def test_ops_are_registered_with_schemas():
         schema = str(op.default._schema)
         assert schema.startswith("pof::" + name + "("), schema
     assert "Tensor? g_band" in str(torch.ops.pof.spatial_attention_backward.default._schema)
+    bn = str(torch.ops.pof.bn_lrelu_pool.default._schema)
+    assert "running_mean" in bn and "!" in bn and "groups=1" in bn        # mutates its running statistics
+
+
+def test_training_ops_fake_kernels():
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        y = torch.empty(90, 64, 48, device="cuda")
+        g = torch.empty(64, device="cuda")
+        z, mu, istd = torch.ops.pof.bn_lrelu_pool(y, g, g, None, None, 0.1, 1e-5, 0.1, True, 3)
+        assert tuple(z.shape) == (90, 64, 24) and tuple(mu.shape) == tuple(istd.shape) == (3 * 64,)
+        dy, dg, db, ds = torch.ops.pof.bn_lrelu_pool_backward(y, z, g, g, mu, istd, 0.1, True, True, 3)
+        assert dy.shape == y.shape and tuple(dg.shape) == tuple(db.shape) == tuple(ds.shape) == (64,)
+        dw = torch.ops.pof.conv3_wgrad(torch.empty(90, 32, 48, device="cuda"), y)
+        assert tuple(dw.shape) == (64, 32, 3)
 
 
 def test_fake_kernels_give_the_output_shapes_without_running_anything():
