@@ -18,6 +18,7 @@
 //   * epilogue: y = acc * scale[co] + shift[co] (BatchNorm folded with the conv bias), LeakyReLU,
 //     optional max over position pairs (adjacent lanes), store.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "pof_common.h"
@@ -409,6 +410,13 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
         // summation order, bit-identical results
         int ct = Co <= 64 ? 2 : 4;
         while (ct > 1 && gx * ((Co + 32 * ct - 1) / (32 * ct)) < kCvFillWorkgroups) ct >>= 1;
+        // fewer than two resident rounds of 128-channel workgroups (4 per CU x 256 CUs): the last, partly filled round
+        // costs a whole round -- 64-channel workgroups quantise finer (measured at S = 3600, one scan of a training
+        // batch: 256 -> 256 L = 14 0.234 -> 0.218 ms, 512 -> 256 L = 14 0.425 -> 0.390, 256 -> 128 L = 28 0.214 -> 0.195;
+        // tools/exp_conv_ct.py), at equal summation order
+        if (ct == 4 && gx * ((Co + 127) / 128) < 8 * kCvFillWorkgroups) ct = 2;
+        { static const int force = [] { const char *e = getenv("POF_CONV_CT"); return e ? atoi(e) : 0; }();
+          if (force == 1 || force == 2 || force == 4) ct = (Co <= 32 && force > 1) ? 1 : (Co <= 64 && force > 2) ? 2 : force; }
         const long long wgs = gx * ((Co + 32 * ct - 1) / (32 * ct));
         const int nchunk = (Ci + kCvCC - 1) / kCvCC;
         if (wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves && tiles <= 0x7fffffffLL) {
