@@ -1,6 +1,8 @@
+"""Trunk conv layers at S sequences per launch with the channel-group size chosen by the library or forced
+(POF_CONV_CT=4|2|1): the launch-quantisation experiment behind the 64-channel rule of pof_conv3_bn_lrelu.
+    python tools/exp_conv_ct.py 3600"""
 import os, sys
-sys.path.insert(0, "/root/repo")
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from planar_optical_flow_amd import ops
 S = int(sys.argv[1])
