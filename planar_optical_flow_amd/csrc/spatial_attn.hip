@@ -245,7 +245,9 @@ int dispatch_merge(int W, const T *x, const T *tmpl, const float *prob, T *out, 
     // shorter segments (more workgroups, a little halo re-read) for small batches
     const long long colblocks = (F / 4 + 127) / 128;
     int L = N;
-    while (L > 32 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
+    // small batches: segments down to 8 points (a 10-row halo per segment re-read from L2) -- at one scan per call the
+    // walk is bound by its 105 workgroups, not by bytes: B = 1 forward 37 -> 27 us, B = 8 69 -> 46 us (tools/exp_attn_small.py)
+    while (L > 8 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
     switch (W) {
         case 1: launch_merge<1, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
         case 3: launch_merge<3, TRANS, T>(x, tmpl, prob, out, out2, B, N, F, L, alpha, s); break;
@@ -669,7 +671,9 @@ extern "C" int pof_spatial_attention_backward_fused(const float *emb_x, const fl
         // segment length as for the merge kernel: whole scan per lane when the batch alone fills the chip
         const long long colblocks = (F / 4 + 127) / 128;
         int L = N;
-        while (L > 32 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
+            // the fused walk carries two rings: 16-point segments are its optimum at small batches (B = 1 70 -> 57 us;
+        // 8-point segments lose again at B = 8)
+        while (L > 16 && colblocks * ((N + L - 1) / L) * B < 3072) L = (L + 1) / 2;
         switch (W) {
             case 1: launch_bwd_fused<1>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
             case 3: launch_bwd_fused<3>(g_out, tmpl, prob, d_tmpl, d_x, partial, B, N, F, L, alpha, s); break;
