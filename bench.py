@@ -70,14 +70,17 @@ def parse():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--batch", type=int, default=BATCH)
-    ap.add_argument("--ring", type=int, default=8, help="distinct resident batches cycled through")
+    ap.add_argument("--ring", type=int, default=16,
+                    help="distinct resident batches cycled through (>= 2 x slots: a launch streams `slots` of them "
+                         "and evaluates the params of the next `slots`)")
+    ap.add_argument("--dets-per-sample", type=int, default=-1,
+                    help="ablation: exactly this many detections per sample instead of the synthetic 0..6 legs")
+    ap.add_argument("--no-params", action="store_true",
+                    help="ablation: the timed launches do not evaluate the next slots' params (they are constant)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--streams", type=int, default=4,
-                    help="independent batches in flight: batch i is launched on stream i %% S and evaluates the params "
-                         "of batch i + S (the dependent-launch boundary and the ramp / tail of one batch's launch "
-                         "are covered by the next batch's; 1: one launch at a time)")
-    ap.add_argument("--no-chain", dest="chained", action="store_false",
-                    help="two launches per step (params + streaming) instead of the chained single launch")
+    ap.add_argument("--slots", type=int, default=8,
+                    help="ring slots (batches) handed to ONE launch of pof_scan_preprocess_multi; a step is still one "
+                         "batch: K steps = ceil(K / slots) launches (1: one launch per batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-model", action="store_true",
                     help="skip the DR-SPAAM forward extra (PMC passes: keeps the per-kernel averages per shape)")
@@ -232,6 +235,12 @@ def main():
     from planar_optical_flow_amd import synth
     B, N = a.batch, N_PTS
     sb = synth.make_batch(seed=2 + 1000 * rank, B=B, T=2, N=N)
+    if a.dets_per_sample >= 0:
+        rs = np.random.default_rng(99 + rank)
+        for b in range(B):
+            d = np.stack([rs.uniform(1.0, 10.0, a.dets_per_sample),
+                          rs.uniform(sb.phi[0], sb.phi[-1], a.dets_per_sample)], axis=1)
+            sb.dets[b] = {"wc": np.zeros((0, 2)), "wa": np.zeros((0, 2)), "wp": d}
     # CPU baseline first: the worker pool is forked before this process touches the GPU
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -261,12 +270,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(sbm, n_streams):
-        """Ring of resident batches + hipGraph of one trip round it; W warm-up steps, then `repeats` timed regions
-        of EXACTLY K steps, each bracketed by barrier + synchronize, wall time maximised over ranks.
-        -> dict(wall_s [repeats], dev_ms [repeats], ring)"""
+    def measure(sbm, slots, out_dtype=torch.float32):
+        """Ring of resident batches; K steps = ceil(K / slots) launches of pof_scan_preprocess_multi, each streaming
+        up to `slots` ring slots and evaluating the params of as many slots further round the ring; the K-step
+        region (and the W warm-up steps) captured as one hipGraph on the current stream.  W warm-up steps, then
+        `repeats` timed regions of EXACTLY K steps, each bracketed by barrier + synchronize, wall time maximised
+        over ranks.  -> dict(wall_s [repeats], dev_ms [repeats], ring)"""
         Bm = len(sbm.scans)
         offs, rphi, _ = sbm.det_csr()
+        S = max(1, min(slots, a.ring // 2, 8))
         ring = []
         for r in range(a.ring):
             sh = (r * 509) % Bm  # distinct memory and distinct content per ring slot
@@ -279,54 +291,32 @@ def main():
             rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
             det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
             outs = {
-                "flow": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
+                "flow": torch.empty((Bm, N, 2), dtype=out_dtype, device=dev),
                 "target_cls": torch.empty((Bm, N), dtype=torch.int64, device=dev),
                 "target_reg": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
                 "exclude_mask": torch.empty((Bm, N), dtype=torch.float32, device=dev),
             }
             ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, len(rr)), dtype=torch.uint8, device=dev)
-            ring.append((scans, o0, o1, det, outs, ws))
-
-        S = max(1, min(n_streams, a.ring)) if a.chained else 1
-        assert a.ring % S == 0, "--ring must be a multiple of --streams"
-
-        def step(i, phases=3):
-            scans, o0, o1, det, outs, ws = ring[i % a.ring]
-            if a.chained and phases == 3:
-                # one launch: stream batch i (its params were produced by launch i - S) and evaluate the params
-                # of batch i + S on extra workgroups of the same grid
-                _, n0, n1, ndet, _, nws = ring[(i + S) % a.ring]
-                ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws,
-                                    next_batch={"odom0": n0, "odom1": n1, "dets": ndet, "workspace": nws})
-            else:
-                ops.scan_preprocess(scans, tab, o0, o1, det, want=want, out=outs, workspace=ws, phases=phases)
-
-        if a.chained:
-            for k in range(S):
-                step(k, phases=1)  # prime the chains: params of the first S ring slots
-        lanes = [torch.cuda.Stream(device=dev) for _ in range(S)] if S > 1 else []
+            ring.append({"scans": scans, "odom0": o0, "odom1": o1, "dets": det, "out": outs, "workspace": ws})
 
         def trip(n):
-            """n consecutive steps; with S > 1 step i goes to stream i % S (independent batches, each stream's
-            chain is ordered by the stream), forked from and joined to the current stream."""
-            if S == 1:
-                for i in range(n):
-                    step(i)
-                return
-            cur = torch.cuda.current_stream()
-            for ln in lanes:
-                ln.wait_stream(cur)
-            for i in range(n):
-                with torch.cuda.stream(lanes[i % S]):
-                    step(i)
-            for ln in lanes:
-                cur.wait_stream(ln)
+            """n consecutive steps from ring position 0: launches of up to S slots; a launch that streams slots
+            [p, p + m) evaluates the params of slots [p + S, p + S + m) -- every step's params are evaluated once,
+            S steps before the step that consumes them."""
+            p = 0
+            while n > 0:
+                m = min(S, n)
+                cur = [ring[(p + j) % a.ring] for j in range(m)]
+                nxt = [] if a.no_params else [ring[(p + S + j) % a.ring] for j in range(m)]
+                ops.scan_preprocess_multi(cur, tab, next_batches=nxt, want=want, out_dtype=out_dtype)
+                p += m
+                n -= m
+
+        # prime: params of the first S slots (with --no-params: of all of them, once)
+        for r0 in range(0, a.ring if a.no_params else S, S):
+            ops.scan_preprocess_multi([], tab, next_batches=ring[r0:r0 + S], want=want, out_dtype=out_dtype)
 
         # ---- hipGraphs: the K-step region (and the W warm-up steps) are captured whole -------------
-        # One replay = up to kGraphSteps consecutive steps (a longer region is replayed in pieces): with several
-        # streams every replay forks and joins its branches once, ~18 us, which a graph of only one trip round
-        # the ring (8 steps) does not amortise (tools/ubench/headline_abl.hip: 13.3 us per step against 12.0 us for
-        # 64 steps per replay and 11.1 us free-running).
         kGraphSteps = 512
         graphs = {}
 
@@ -363,10 +353,7 @@ def main():
                 if rem:
                     graphs[rem].replay()
             else:
-                full, rem = divmod(k, a.ring)
-                for _ in range(full):
-                    trip(a.ring)
-                trip(rem)
+                trip(k)
 
         run(a.warmup)
         walls, devs = [], []
@@ -385,11 +372,18 @@ def main():
                 dt = float(t.item())
             walls.append(dt)
             devs.append(ev0.elapsed_time(ev1))
-        return {"wall_s": walls, "dev_ms": devs, "ring": ring, "graph": graph is not None, "streams": S}
+        return {"wall_s": walls, "dev_ms": devs, "ring": ring, "graph": graph is not None, "slots": S,
+                "launches": -(-a.steps // S)}
 
-    weak = measure(sb, a.streams)
-    # the same steps one launch at a time (the per-kernel duration rocprofv3 reports is comparable with THIS)
-    single = measure(sb, 1) if (a.streams > 1 and a.chained) else None
+    weak = measure(sb, a.slots)
+    # the same steps one batch per launch (the per-kernel duration rocprofv3 reports for THAT form is one step)
+    single = measure(sb, 1) if a.slots > 1 else None
+    # the float64-output instantiation (the reference's float64 operation order for the flow: utils.py:47-48,
+    # 639-662), same region shape
+    f64 = measure(sb, a.slots, torch.float64)
+    f64_out = f64["ring"][0]["out"]["flow"][:64].cpu().numpy()
+    f64 = {k: v for k, v in f64.items() if k != "ring"}
+    torch.cuda.empty_cache()
     dt = float(np.median(weak["wall_s"]))
     dev_ms = float(np.median(weak["dev_ms"]))
     ring = weak["ring"]
@@ -403,7 +397,7 @@ def main():
         import copy
         sbs = copy.copy(sbg)
         sbs.scans, sbs.odom0, sbs.odom1, sbs.dets = sbg.scans[sl], sbg.odom0[sl], sbg.odom1[sl], sbg.dets[sl]
-        st = measure(sbs, a.streams)
+        st = measure(sbs, a.slots)
         sdt = float(np.median(st["wall_s"]))
         strong = {"value": B * a.steps / sdt, "unit": "scans/s", "ms_per_step": sdt / a.steps * 1e3,
                   "scans_per_rank_per_step": per, "global_batch": B,
@@ -412,15 +406,16 @@ def main():
 
     # ---- parity of what was just computed (outside the timed region) ------------
     from oracle import ref_numpy as R
-    scans, o0, o1, det, outs, _ = ring[0]
+    outs = ring[0]["out"]
     phi = R.laser_phi()
     flow = outs["flow"][:64].cpu().numpy()
-    epe = 0.0
+    epe = epe64 = 0.0
     for b in range(64):
         cur = sb.scans[b, -1]
         xy = np.array(R.polar_to_xy(cur, phi)).T
         ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
+        epe64 += float(np.linalg.norm(f64_out[b] - ref, axis=-1).mean()) / 64
 
     # the training rows run on all ranks (they hold collectives).  They are extras: an error in one of them (the
     # same on every rank) is reported in its place instead of costing the line its headline measurement
@@ -441,14 +436,19 @@ def main():
         # algorithmic bytes per scan: 4N range row in; out 8N flow f32 +
         # 8N target_cls int64 + 8N target_reg + 4N exclude mask  = 32N = 14 400 B
         bytes_per_scan = 4 * N + (8 + 8 + 8 + 4) * N
-        launch_ms = dev_ms / a.steps
-        achieved = bytes_per_scan * B / (launch_ms * 1e-3) / 1e9
-        kernel = "scan_flat_kernel<float>" if a.chained else "scan_params_kernel + scan_flat_kernel<float>"
-        traffic, traffic_src = pmc_traffic(("scan_flat_kernel<float>",) if a.chained
-                                           else ("scan_params_kernel", "scan_flat_kernel<float>"))
+        bytes_per_scan_f64 = 4 * N + (16 + 8 + 8 + 4) * N      # float64 flow: 40N = 18 000 B
+        S = weak["slots"]
+        walls = weak["wall_s"]
+        ms_step = dt / a.steps * 1e3
+        # ONE clock: the roofline figure comes from the same wall interval as ms_per_step (barrier + synchronize on
+        # both sides, graph launch and the final synchronize included); the HIP-event interval on the launch
+        # stream is carried beside it
+        achieved = bytes_per_scan * B / (ms_step * 1e-3) / 1e9
+        ev_step = dev_ms / a.steps
+        kernel = "scan_flat_kernel<float, headline cfg>"
+        traffic, traffic_src = pmc_traffic(("scan_flat_kernel<float",))
         if B != BATCH:
             traffic = None
-        walls = weak["wall_s"]
         result = {
             "metric": "scans/sec, flow-only preprocess of 450-pt synthetic scan pairs, batch 4096 per GPU "
                       "(+ flow EPE vs reference oracle)",
@@ -457,11 +457,12 @@ def main():
             "n_gpus": world,
             "steps": a.steps,
             "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
+            "ms_per_step": ms_step,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": "f32 flow arithmetic (float32 outputs) + f64 exact association / mask decisions; the float64-"
+                     "output instantiation (the reference's float64 operation order) is `value_f64`",
             "data": "synthetic",
             "timed_repeats": len(walls),
             "ms_per_step_min": min(walls) / a.steps * 1e3,
@@ -470,12 +471,11 @@ def main():
                                    "(A1-A7 fused: xy, displacement flow, canonical frame, association, "
                                    "regression target, exclude mask), float32 outputs" % B,
                        "global_batch": world * B, "ring_batches": a.ring,
-                       "launch": ("eager" if not graph else "hipGraph replay")
-                                 + (", chained (the params of batch i+%d ride in the launch of batch i)" % weak["streams"]
-                                    if a.chained else "")
-                                 + (", %d independent batches in flight on %d HIP streams" % (weak["streams"], weak["streams"])
-                                    if weak["streams"] > 1 else ""),
-                       "streams": weak["streams"],
+                       "launch": ("eager" if not graph else "hipGraph replay of the K-step region")
+                                 + ", pof_scan_preprocess_multi: %d ring slot(s) per launch (%d launches for %d steps), "
+                                   "the params of the slots %d further round the ring ride in the same launch"
+                                   % (S, weak["launches"], a.steps, S),
+                       "slots_per_launch": S,
                        "parallelism": "weak: batch-sharded x%d, %d scans per rank and step, no data-path collective" % (world, B),
                        "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else None),
                        "collective_backend": (backend if world > 1 else None)},
@@ -484,22 +484,37 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": traffic_src,
-                         "bytes_per_launch": bytes_per_scan * B, "launch_ms": launch_ms,
-                         "launch_ms_min": min(weak["dev_ms"]) / a.steps, "launch_ms_max": max(weak["dev_ms"]) / a.steps,
-                         "concurrent_launches": weak["streams"],
-                         "note": ("launch_ms = device time of the timed region / launches" +
-                                  ("; %d launches (independent batches) are in flight at a time, so a per-kernel "
-                                   "duration as rocprofv3 lists it is about %d x launch_ms -- compare it with "
-                                   "single_stream.launch_ms" % (weak["streams"], weak["streams"])
-                                   if weak["streams"] > 1 else ""))},
+                         "clock": "wall (the interval of ms_per_step)",
+                         "bytes_per_step": bytes_per_scan * B,
+                         "bytes_per_launch": bytes_per_scan * B * S, "launch_ms": ms_step * S,
+                         "steps_per_launch": S,
+                         "events": {"ms_per_step": ev_step, "achieved": bytes_per_scan * B / (ev_step * 1e-3) / 1e9,
+                                    "frac": bytes_per_scan * B / (ev_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "ms_per_step_min": min(weak["dev_ms"]) / a.steps,
+                                    "ms_per_step_max": max(weak["dev_ms"]) / a.steps,
+                                    "note": "HIP events on the launch stream around the same K-step region"},
+                         "note": "one kernel launch covers %d steps (ring slots): a per-kernel duration as rocprofv3 "
+                                 "lists it is launch_ms = %d x ms_per_step; `traffic` is per launch as well" % (S, S)},
         }
+        f_dt = float(np.median(f64["wall_s"]))
+        f_ms = f_dt / a.steps * 1e3
+        f_ach = bytes_per_scan_f64 * B / (f_ms * 1e-3) / 1e9
+        result["value_f64"] = world * B * a.steps / f_dt
+        result["roofline_f64"] = {"bound": "hbm", "kernel": "scan_flat_kernel<double, headline cfg>",
+                                  "dtype": "f64 flow arithmetic in the reference's operation order, float64 flow output",
+                                  "ms_per_step": f_ms, "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": f_ach / HBM_PEAK_GBS, "bytes_per_step": bytes_per_scan_f64 * B,
+                                  "steps_per_launch": f64["slots"], "clock": "wall",
+                                  "events_ms_per_step": float(np.median(f64["dev_ms"])) / a.steps,
+                                  "epe_vs_oracle_m": epe64, "traffic": None}
         if single is not None:
             s_dev = float(np.median(single["dev_ms"])) / a.steps
             s_wall = float(np.median(single["wall_s"]))
-            s_ach = bytes_per_scan * B / (s_dev * 1e-3) / 1e9
-            result["single_stream"] = {"value": world * B * a.steps / s_wall, "ms_per_step": s_wall / a.steps * 1e3,
-                                       "launch_ms": s_dev, "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
-                                       "note": "the same K steps, one launch at a time on one stream"}
+            s_ach = bytes_per_scan * B / (s_wall / a.steps) / 1e9
+            result["single_batch_launches"] = {"value": world * B * a.steps / s_wall, "ms_per_step": s_wall / a.steps * 1e3,
+                                               "achieved": s_ach, "frac": s_ach / HBM_PEAK_GBS,
+                                               "events_ms_per_step": s_dev,
+                                               "note": "the same K steps as K launches of one ring slot each"}
         if strong is not None:
             result["strong_scaling"] = strong
         if box is not None:
@@ -573,6 +588,17 @@ def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
         step()
     barrier()
     dt = (time.perf_counter() - t0) / steps
+    # host synchronisations in one eager step (forward, backward, SyncBatchNorm / gradient collectives, Adam):
+    # sync debug mode "error" raises on any blocking call
+    host_syncs = 0
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        step()
+    except RuntimeError as e:       # noqa: BLE001
+        host_syncs = "at least one (%s)" % str(e).splitlines()[0][:80]
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    barrier()
     ar_ms = None
     if world > 1:
         for _ in range(3):
@@ -588,33 +614,45 @@ def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     graphed = None
-    if world == 1:
+    if world == 1 or backend == "nccl":
         # the same step as ONE hipGraph replay (graph_step.GraphedTrainStep): ~150 small kernels, eager pacing is the
-        # host's.  Single process only: with more ranks the step holds collectives (SyncBatchNorm in the forward),
-        # which are not captured.
+        # host's.  With more ranks the SyncBatchNorm collectives and the gradient all-reduce are nodes of the graph
+        # (RCCL is stream-ordered and capturable); a host-side backend (the gloo rehearsal) cannot be captured.
         from planar_optical_flow_amd.graph_step import GraphedTrainStep
         torch.manual_seed(4)
-        gmodel = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).to(dev).train()
+        gmodel = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).to(dev)
+        greducer = None
+        if world > 1:
+            pdist.broadcast_parameters(gmodel)
+            pdist.convert_sync_batchnorm(gmodel)
+            greducer = pdist.GradientAllReduce(gmodel)
+        gmodel.train()
         goptim = Optim(gmodel, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
-        gstep = GraphedTrainStep(gmodel, goptim.make_capturable(), {"input": x, "target": y})
+        gstep = GraphedTrainStep(gmodel, goptim.make_capturable(), {"input": x, "target": y}, reducer=greducer)
         batch = {"input": x, "target": y}
         for _ in range(warm):
             goptim.set_lr(0)
             gstep(batch)
-        torch.cuda.synchronize()
+        barrier()
         t0 = time.perf_counter()
         for _ in range(10 * steps):
             goptim.set_lr(0)
             gstep(batch)
-        torch.cuda.synchronize()
+        barrier()
         gdt = (time.perf_counter() - t0) / (10 * steps)
-        graphed = {"ms_per_step": gdt * 1e3, "samples_per_s": per / gdt,
-                   "note": "zero_grad + forward + backward + Adam captured once, replayed per batch (inputs copied "
-                           "into static buffers, learning rate a device scalar)"}
-    nbytes = reducer.bucket.numel() * 4
+        if world > 1:
+            t = torch.tensor([gdt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gdt = float(t.item())
+        graphed = {"ms_per_step": gdt * 1e3, "samples_per_s": world * per / gdt,
+                   "note": "zero_grad + forward + backward%s + Adam captured once, replayed per batch (inputs copied "
+                           "into static buffers, learning rate a device scalar)"
+                           % (" + SyncBatchNorm collectives + gradient all-reduce (RCCL nodes of the graph)" if world > 1 else "")}
+    nbytes = (reducer.bucket.numel() - 1) * 4       # the last element is the agreed stop flag
     return {"workload": "BASELINE configs[3]: box-regression head training step, batch 256 per rank x %d rank(s), "
                         "64-point segments, Adam(amsgrad), one flat gradient all-reduce, global-batch BatchNorm" % world,
             "ms_per_step": dt * 1e3, "samples_per_s": world * per / dt, "per_rank_batch": per, "graphed": graphed,
+            "host_syncs_per_step": host_syncs,
             "grad_allreduce_ms": ar_ms, "grad_bucket_bytes": nbytes,
             "grad_allreduce_busbw_GBps": (2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9) if ar_ms else None,
             "collective_backend": backend if world > 1 else None}
@@ -673,7 +711,7 @@ def bench_detector_train(ops, synth, tab, dev, world, rank, backend, barrier, st
     return {"workload": "BASELINE configs[2], training: DR-SPAAM step (cutout + forward + backward + gradient "
                         "all-reduce + Adam), %d windows x %d scans x %d points per rank x %d rank(s)" % (B, T, N, world),
             "ms_per_step": dt * 1e3, "scans_per_s": world * B / dt, "per_rank_batch": B,
-            "grad_bucket_bytes": reducer.bucket.numel() * 4,
+            "grad_bucket_bytes": (reducer.bucket.numel() - 1) * 4,
             "trunk": "HIP: conv3 forward / dgrad (conv3_kernel), wgrad (conv3_wgrad_kernel), BatchNorm(train) + "
                      "LeakyReLU + max-pool forward / backward (bn_* kernels)",
             "collective_backend": backend if world > 1 else None}

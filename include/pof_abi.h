@@ -144,6 +144,35 @@ int pof_scan_preprocess_chained(const float *ranges, long long sample_stride, in
                                 void *workspace, size_t workspace_bytes, const pof_scan_inputs *next,
                                 pof_stream_t stream);
 
+/* Several batches per launch (round 3).  A data loader that runs ahead hands over up to
+ * POF_SCAN_MAX_SLOTS ring slots at once: ONE launch streams the n_cur batches `cur` (their workspaces must hold
+ * their params) and evaluates the params of the n_next batches `next` on extra workgroups, as the chained form
+ * does for one.  All batches of a call share N, the angle table, flow_kind / canonical / out_f64, the class
+ * constants and the SET of non-NULL outputs (POF_E_BADARG otherwise); B may differ.  n_cur == 0: params only.
+ * tab_cs_f32: optional [N][2] float32 copy of the table's (cos, sin) pairs, each rounded once from the float64
+ * entry (what the float32-output kernel would otherwise convert per point); NULL is allowed.
+ * Shapes: N even, N >= 128 (POF_E_SHAPE otherwise: use pof_scan_preprocess_chained), sample_stride even.
+ * Replaces the same reference calls as pof_scan_preprocess (dataset_dr_spaam.py:384-409), for a window of
+ * consecutive DataLoader batches (dataset_dr_spaam.py:26-28, prefetching workers). */
+#define POF_SCAN_MAX_SLOTS 8
+typedef struct pof_scan_batch {
+    const float *ranges;               /* row b at ranges + b * sample_stride */
+    long long sample_stride;
+    int32_t B, D;
+    const int32_t *det_offsets;        /* [B+1] or NULL */
+    void *xy, *flow;                   /* [B][N][2] float32 / float64 (out_f64), or NULL */
+    int64_t *closest, *target_cls;     /* [B][N] or NULL */
+    float *target_reg;                 /* [B][N][2] or NULL */
+    float *dyn_mask, *valid_mask, *exclude_mask;   /* [B][N] or NULL */
+    void *workspace;
+    size_t workspace_bytes;
+} pof_scan_batch;
+
+int pof_scan_preprocess_multi(const pof_scan_batch *cur, int n_cur, const pof_scan_inputs *next, int n_next,
+                              int N, const double *tab, const float *tab_cs_f32, int flow_kind, int canonical,
+                              int out_f64, const double *assoc_radius, const int32_t *labels,
+                              const double *dyn_radius, pof_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * A3 on caller-supplied scanner-frame points (the reference's own signature):
  *   get_displacement_from_odometry(scan1_xy, odom0, odom1)   src/utils/utils.py:639-662

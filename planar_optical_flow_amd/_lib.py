@@ -32,6 +32,7 @@ SIGNATURES = {
                                          _p, _p, _p, _p, _p, _p, _p, _sz, _p, _p]),
     "pof_scan_preprocess": (_i, [_p, _ll, _i, _i, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _i, _p, _p, _p,
                                  _p, _p, _p, _p, _p, _p, _p, _sz, _p]),
+    "pof_scan_preprocess_multi": (_i, [_p, _i, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p, _p]),
     "pof_flow_from_xy": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _p]),
     "pof_xy_to_rphi": (_i, [_p, _p, _p, _p, _ll, _p]),
     "pof_rotate_flow": (_i, [_p, _p, _p, _i, _i, _i, _i, _p]),
@@ -81,6 +82,18 @@ class ScanInputs(C.Structure):
                 ("flow_kind", C.c_int32), ("want_flow", C.c_int32), ("assoc_radius", C.c_double * 3),
                 ("labels", C.c_int32 * 3), ("pad_", C.c_int32), ("dyn_radius", C.c_double * 3),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class ScanBatch(C.Structure):
+    """pof_scan_batch of include/pof_abi.h."""
+    _fields_ = [("ranges", C.c_void_p), ("sample_stride", C.c_longlong), ("B", C.c_int32), ("D", C.c_int32),
+                ("det_offsets", C.c_void_p), ("xy", C.c_void_p), ("flow", C.c_void_p), ("closest", C.c_void_p),
+                ("target_cls", C.c_void_p), ("target_reg", C.c_void_p), ("dyn_mask", C.c_void_p),
+                ("valid_mask", C.c_void_p), ("exclude_mask", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+SCAN_MAX_SLOTS = 8
 
 
 class PofError(RuntimeError):

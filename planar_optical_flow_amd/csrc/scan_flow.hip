@@ -59,12 +59,23 @@ struct PreArgs {
 
 constexpr int kDetStride = 6;
 constexpr int kInline = 8;   // detections stored inline in the per-sample record
-// per-sample record (doubles): [0,8) motion[7] + detection count; [8, 56) kInline detections x kDetStride;
-// then the float32 companions the flat kernel stages without arithmetic: [56, 60) = 8 floats of motion,
-// [60, 84) = kInline x 6 floats {cx, cy, Dlo, Dhi, A, pad} (the screen of screen_entry below)
-constexpr int kRecF32Mot = 8 + kInline * kDetStride;
-constexpr int kRecF32Det = kRecF32Mot + 4;
-constexpr int kRecStride = kRecF32Det + kInline * 3;
+// Per-sample record, kRecStride doubles = 832 bytes:
+//   float64 part  [0, 8)   motion[7] + detection count
+//                 [8, 56)  kInline detections x kDetStride {cx, cy, assoc radius, dyn s-thr, label, assoc s-thr}
+//   flat image    (384 contiguous bytes: what a wave of the flat kernel copies into LDS, 24 lanes x 16 bytes)
+//                 +0    float32 header, 16 floats: [0,7) motion, [7] detection count (int bits), [8,10) class of
+//                       the inline detections (8 x u8), [10,12) "far" flag of the inline detections (8 x u8)
+//                 +64   kInline x float4 {cx, cy, -sd, 0}: the float32 screen (flat_run); unused slots hold the
+//                       null entry {0, 0, +inf, 0}
+//                 +192  kInline x {cx, cy} float64: centres of the inline detections
+//                 +320  motion[7] + detection count, float64 (float64-output kernels)
+constexpr int kRecImg = 8 + kInline * kDetStride;           // in doubles: byte 448
+constexpr int kRecHdrFloats = 16;
+constexpr int kImgScreen = kRecHdrFloats * 4;               // byte offsets inside the image
+constexpr int kImgCtr = kImgScreen + 16 * kInline;          // 192
+constexpr int kImgMot = kImgCtr + 16 * kInline;             // 320
+constexpr int kImgBytes = kImgMot + 64;                     // 384
+constexpr int kRecStride = kRecImg + kImgBytes / 8;         // 104 doubles
 
 // Per-sample rigid motion from the two (sin, cos) pairs the params kernel
 // evaluates on two lanes.  mot[0..3] = 2x2 matrix (row major), mot[4..5] =
@@ -167,46 +178,37 @@ __device__ __forceinline__ void apply_motion(int kind, double px, double py, dou
 //   ws_det[g] = every detection (CSR order), read only by samples with more
 //               than kInline detections.
 // detection entry = { cx, cy, assoc radius, dyn s-threshold, label, assoc s-threshold }
-__device__ __forceinline__ void det_entry(const PreArgs &a, int g, double *w)
+// AP: pointer to the arguments -- a plain pointer to a by-value kernel argument, or a constant-address-space
+// pointer into the kernel-argument segment (slot chosen at run time, scan_flat_kernel)
+template <typename AP>
+__device__ __forceinline__ void det_entry(AP a, int g, double *w)
 {
-    const double dr = a.det_rphi[2 * g], dp = a.det_rphi[2 * g + 1];
+    const double dr = a->det_rphi[2 * g], dp = a->det_rphi[2 * g + 1];
     double s, c;
     sincos(dp, &s, &c);
-    const int cl = a.det_cls[g];
+    const int cl = a->det_cls[g];
     w[0] = dr * c;
     w[1] = dr * s;
-    w[2] = cl == 0 ? a.ra0 : (cl == 1 ? a.ra1 : a.ra2);
-    w[3] = cl == 0 ? a.sd0 : (cl == 1 ? a.sd1 : a.sd2);   // dist <= dyn radius   <=>  s <= w[3]
-    w[4] = (double)(cl == 0 ? a.lb0 : (cl == 1 ? a.lb1 : a.lb2));
-    w[5] = cl == 0 ? a.sa0 : (cl == 1 ? a.sa1 : a.sa2);   // dist <  assoc radius <=>  s <= w[5]
+    w[2] = cl == 0 ? a->ra0 : (cl == 1 ? a->ra1 : a->ra2);
+    w[3] = cl == 0 ? a->sd0 : (cl == 1 ? a->sd1 : a->sd2);   // dist <= dyn radius   <=>  s <= w[3]
+    w[4] = (double)(cl == 0 ? a->lb0 : (cl == 1 ? a->lb1 : a->lb2));
+    w[5] = cl == 0 ? a->sa0 : (cl == 1 ? a->sa1 : a->sa2);   // dist <  assoc radius <=>  s <= w[5]
 }
 
-// float32 screen of one detection against float32 squared distances s2f.  With all coordinates below
-// 100 m, |s2f - s2| <= 1e-3 + 1e-4 * s2 (s2 = the float64 squared distance the reference's decision is
-// made on; derivation in DESIGN.md section 3.1), hence
-//   s2f <= Dlo = sd (1 - 1e-4) - 1e-3   =>  s2 <= sd   (surely inside the dynamic-mask radius)
-//   s2f >  Dhi = sd (1 + 1e-4) + 1e-3   =>  s2 >  sd   (surely outside)
-//   s2f >  A   = sa (1 + 1e-4) + 1e-3   =>  s2 >  sa   (surely not an association candidate)
-// Dlo is rounded down, Dhi and A up.  A far detection gets (-inf, +inf, +inf): never decided here.
-__device__ __forceinline__ float round_dn(double v)
+// float32 screen of the flat kernel (flat_screen).  For a detection j the kernel tracks
+//   dd_j = fl(ex*ex + fl(ey*ey - sd_j))     ex, ey = float32 point - float32 centre, sd_j rounded to float32
+// and keeps the minimum over the sample's inline detections.  With all coordinates below 100 m and sd <= 400 m^2,
+// |dd_j - (s2_j - sd_j)| <= E(s2_j) = 1e-3 + 1e-4 * s2_j, where s2_j is the float64 squared distance the
+// reference's decision is made on (derivation in DESIGN.md section 3.1).  Hence, with M_j = 1e-3 + 1e-4 * sd_j:
+//   dd_j <= -M_j  =>  s2_j <= sd_j   (surely inside the dynamic-mask radius)
+//   dd_j >   M_j  =>  s2_j >  sd_j   (surely outside)
+//   s2_j <= sa_j (association candidate)  =>  dd_j <= sa_j - sd_j + M_j
+// so the minimum alone decides a point unless it lies in one of the error bands; those points, every point
+// beyond 100 m, and all points of a sample with a "far" detection (centre beyond 100 m or sd > 400) take the
+// exact float64 loop.
+__device__ __forceinline__ bool det_is_far(double cx, double cy, double sd)
 {
-    float f = (float)v;
-    if ((double)f > v) f = __uint_as_float(__float_as_uint(f) + (f > 0.0f ? -1 : 1));
-    return f;
-}
-__device__ __forceinline__ float round_up(double v)
-{
-    float f = (float)v;
-    if ((double)f < v) f = __uint_as_float(__float_as_uint(f) + (f >= 0.0f ? 1 : -1));
-    return f;
-}
-__device__ __forceinline__ void screen_entry(double cx, double cy, double sd, double sa, float4 *e, float *ea)
-{
-    const bool far = !(fabs(cx) + fabs(cy) < 100.0);
-    const float dlo = round_dn(sd * (1.0 - 1e-4) - 1e-3), dhi = round_up(sd * (1.0 + 1e-4) + 1e-3);
-    const float aa = round_up(sa * (1.0 + 1e-4) + 1e-3);
-    *e = make_float4((float)cx, (float)cy, far ? -INFINITY : dlo, far ? INFINITY : dhi);
-    *ea = far ? INFINITY : aa;
+    return !(fabs(cx) + fabs(cy) < 100.0) || !(sd <= 400.0);
 }
 
 // number of params jobs of a batch: 2 per sample (the two motion angles) + kInline
@@ -220,48 +222,67 @@ __host__ __device__ inline int params_job_count(int B, bool have_dets)
 // pairs; then B*kInline detection slots: slot s of a sample evaluates detections
 // s, s+kInline, ... (the first goes into the inline record, and samples with more
 // than kInline detections additionally get all their rows in the CSR table).
-__device__ __forceinline__ void params_work(const PreArgs &a, int t)
+template <typename AP>
+__device__ __forceinline__ void params_work(AP a, int t)
 {
-    const int nm = 2 * a.B;
+    const int nm = 2 * a->B;
     if (t < nm) {
         const int b = t >> 1, which = t & 1;
-        const double *o0 = a.odom0 + 3 * b, *o1 = a.odom1 + 3 * b;
+        const double *o0 = a->odom0 + 3 * b, *o1 = a->odom1 + 3 * b;
         double s = 0.0, c = 1.0;
-        if (a.flow) {
-            const double ang = motion_angle(a.flow_kind, which, o0, o1);
+        if (a->flow) {
+            const double ang = motion_angle(a->flow_kind, which, o0, o1);
             sincos(ang, &s, &c);
         }
         // partner lane (t ^ 1) holds the other angle of the same sample
         const double s_o = __shfl_xor(s, 1, 64), c_o = __shfl_xor(c, 1, 64);
         if (which == 0) {
-            double *rec = a.ws_rec + (long long)b * kRecStride;
-            if (a.flow) {
-                motion_params(a.flow_kind, o0, o1, s, c, s_o, c_o, rec);
-                float *mf = reinterpret_cast<float *>(rec + kRecF32Mot);
+            double *rec = a->ws_rec + (long long)b * kRecStride;
+            unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
+            float *hf = reinterpret_cast<float *>(img);
+            double *m64 = reinterpret_cast<double *>(img + kImgMot);
+            const int cnt = a->det_offsets ? (a->det_offsets[b + 1] - a->det_offsets[b]) : 0;
+            if (a->flow) {
+                motion_params(a->flow_kind, o0, o1, s, c, s_o, c_o, rec);
 #pragma unroll
-                for (int k = 0; k < 7; ++k) mf[k] = (float)rec[k];
+                for (int k = 0; k < 7; ++k) {
+                    hf[k] = (float)rec[k];
+                    m64[k] = rec[k];
+                }
             }
-            rec[7] = a.det_offsets ? (double)(a.det_offsets[b + 1] - a.det_offsets[b]) : 0.0;
+            rec[7] = (double)cnt;
+            m64[7] = (double)cnt;
+            reinterpret_cast<int *>(hf)[7] = cnt;
         }
-    } else if (a.det_offsets && t < nm + a.B * kInline) {
+    } else if (a->det_offsets && t < nm + a->B * kInline) {
         const int u = t - nm;
         const int b = u / kInline, slot = u - b * kInline;
-        const int d0 = a.det_offsets[b], cnt = a.det_offsets[b + 1] - d0;
+        const int d0 = a->det_offsets[b], cnt = a->det_offsets[b + 1] - d0;
+        double *rec = a->ws_rec + (long long)b * kRecStride;
+        unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
+        if (slot >= cnt) {
+            // unused inline slot: the null screen entry (never the minimum), class 0, not far
+            reinterpret_cast<float4 *>(img + kImgScreen)[slot] = make_float4(0.0f, 0.0f, INFINITY, 0.0f);
+            img[32 + slot] = 0;
+            img[40 + slot] = 0;
+        }
         for (int idx = slot; idx < cnt; idx += kInline) {
             double w[kDetStride];
             det_entry(a, d0 + idx, w);
             if (idx < kInline) {
-                double *r = a.ws_rec + (long long)b * kRecStride + 8 + idx * kDetStride;
+                double *r = rec + 8 + idx * kDetStride;
 #pragma unroll
                 for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
-                float4 e;
-                float ea;
-                screen_entry(w[0], w[1], w[3], w[5], &e, &ea);
-                float *f = reinterpret_cast<float *>(a.ws_rec + (long long)b * kRecStride + kRecF32Det) + idx * 6;
-                f[0] = e.x; f[1] = e.y; f[2] = e.z; f[3] = e.w; f[4] = ea; f[5] = 0.0f;
+                const bool far = det_is_far(w[0], w[1], w[3]);
+                reinterpret_cast<float4 *>(img + kImgScreen)[idx] =
+                    make_float4((float)w[0], (float)w[1], far ? INFINITY : -(float)w[3], 0.0f);
+                reinterpret_cast<double2 *>(img + kImgCtr)[idx] = make_double2(w[0], w[1]);
+                const uint8_t cl = a->det_cls[d0 + idx];
+                img[32 + idx] = cl > 1 ? 2 : cl;
+                img[40 + idx] = far ? 1 : 0;
             }
             if (cnt > kInline) {
-                double *r = a.ws_det + (long long)(d0 + idx) * kDetStride;
+                double *r = a->ws_det + (long long)(d0 + idx) * kDetStride;
 #pragma unroll
                 for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
             }
@@ -271,7 +292,7 @@ __device__ __forceinline__ void params_work(const PreArgs &a, int t)
 
 __global__ __launch_bounds__(256) void scan_params_kernel(PreArgs a)
 {
-    params_work(a, blockIdx.x * blockDim.x + threadIdx.x);
+    params_work(&a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // A value that is the same in every lane, moved to scalar registers.
@@ -285,33 +306,35 @@ __device__ __forceinline__ double to_sgpr(double v)
 // Outputs are written once and never re-read by this kernel: streaming (non-temporal)
 // stores keep them from displacing the tables and records in L2 (13.3 vs 16.3 us for the
 // bare I/O shape of the headline launch, tools/ubench/stream_shape.hip).
+// Pointers that were not direct kernel arguments (a batch slot read from the kernel-argument segment) carry no
+// address space: without the cast every access through them is a flat_ instruction (LDS aperture check, counted
+// in both vmcnt and lgkmcnt).
+#define GLOBAL_AS __attribute__((address_space(1)))
 using F4V = float __attribute__((ext_vector_type(4)));
 using F2V = float __attribute__((ext_vector_type(2)));
 using LL2V = long long __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void stream_f4(float *base, long long idx4, float x, float y, float z, float w)
 {
     F4V v = {x, y, z, w};
-    __builtin_nontemporal_store(v, reinterpret_cast<F4V *>(base) + idx4);
+    __builtin_nontemporal_store(v, (GLOBAL_AS F4V *)base + idx4);
 }
 __device__ __forceinline__ void stream_f2(float *base, long long idx2, float x, float y)
 {
     F2V v = {x, y};
-    __builtin_nontemporal_store(v, reinterpret_cast<F2V *>(base) + idx2);
+    __builtin_nontemporal_store(v, (GLOBAL_AS F2V *)base + idx2);
 }
 __device__ __forceinline__ void stream_ll2(long long *base, long long idx2, long long x, long long y)
 {
     LL2V v = {x, y};
-    __builtin_nontemporal_store(v, reinterpret_cast<LL2V *>(base) + idx2);
+    __builtin_nontemporal_store(v, (GLOBAL_AS LL2V *)base + idx2);
 }
 
 template <typename OutT>
 __device__ __forceinline__ void store2(OutT *base, long long idx, double a, double b)
 {
-    using V = typename std::conditional<sizeof(OutT) == 4, float2, double2>::type;
-    V v;
-    v.x = (OutT)a;
-    v.y = (OutT)b;
-    reinterpret_cast<V *>(base)[idx] = v;
+    using V = OutT __attribute__((ext_vector_type(2)));
+    V v = {(OutT)a, (OutT)b};
+    ((GLOBAL_AS V *)base)[idx] = v;
 }
 
 // Launch 2: one workgroup per (SPB samples, 512-point chunk).  Each lane owns
@@ -601,30 +624,67 @@ __device__ __forceinline__ void scan_main(const PreArgs &a, const int block_y)
 }
 
 // ---- flat form of the streaming rows (the headline launch) ---------------------------------------
-// One workgroup chunk = 256 CONSECUTIVE POINTS OF THE FLAT [B*N] AXIS (128 lanes x 2 points), not one
-// sample.  A sample's output rows are 8N = 3600 B (N = 450): with one workgroup per sample every row
-// boundary splits a 128-byte line between two workgroups on different XCDs, and the bare I/O shape of the
-// launch runs at 4.6-4.9 TB/s; with line-aligned 2048-byte (flow / reg / cls) and 1024-byte (mask) chunks
-// the same bytes stream at 6.2-6.3 TB/s (tools/ubench/store_ceiling.hip, profiles/r2_store_*).
-// A chunk touches at most two samples (N >= 256): their records (motion, inline detections) go through
-// LDS, each lane picks its own sample's.  Crowded samples (more than kInline detections) read the rest
-// of their detections from the CSR table in the workspace (L2 hits, exact test only).
+// One WAVE = 64 lanes x 2 points = 128 CONSECUTIVE POINTS OF THE FLAT [B*N] AXIS, not one sample.  A
+// sample's output rows are 8N = 3600 B (N = 450): with one workgroup per sample every row boundary splits a
+// 128-byte line between two workgroups on different XCDs, and the bare I/O shape of the launch runs at
+// 4.6-4.9 TB/s; with line-aligned 1024-byte (flow / reg / cls) and 512-byte (mask) runs per wave the same
+// bytes stream at 6.2-6.3 TB/s (tools/ubench/store_ceiling.hip, profiles/r2_store_*).
+// A wave touches at most two samples (N >= 128 * CPW): it copies the float32 part of their records (motion,
+// screen of the inline detections) and the float64 centres into its OWN slice of LDS -- no workgroup barrier,
+// LDS operations of one wave are ordered -- and each lane picks its own sample's.  Crowded samples (more than
+// kInline detections) read the rest of their detections from the CSR table in the workspace (exact test only).
 //
-// Grid = (P, rows): chunk = x + P * y with P = N / gcd(N, 256) chunks = the period after which the chunks'
-// point-in-scan phases repeat (P * 256 points are a whole number of samples), so that sample and point
-// index follow from small per-phase numbers without a 64-bit division (which alone cost more vector
-// instructions than the flow arithmetic).  Several chunks per workgroup (records and range rows of K
-// chunks requested together) were measured and lost: 15.4 (K = 1) / 16.3 (2) / 19.8 us (4) -- the launch
-// is bound by vector-instruction issue, not by the first memory round trip (profiles/r2_headline_pmc.txt).
-constexpr int kFlatThreads = 128;
+// Round 3: the launch covers up to kMaxSlots (POF_SCAN_MAX_SLOTS) batches (a data loader hands over several ring slots at once):
+// wave-chunk w of the grid belongs to batch k = #{i : wave0[i] <= w}; the batch's pointers are read from the
+// kernel arguments with a scalar-indexed load.  Everything the wave needs per point is a compile-time
+// configuration (CFG >= 0: which outputs exist, flow kind, canonical) or a host-computed constant (the
+// division by N/2 is a multiply-high); CFG < 0 keeps the run-time flags for the remaining combinations.
+constexpr int kMaxSlots = POF_SCAN_MAX_SLOTS;
+constexpr int kWaveLds = 2 * kImgBytes;                    // the flat images of the wave's two samples: 768 B
 
-struct FlatSmem {
-    double mot[2][8];               // motion[7], detection count
-    float motf[2][8];               // float32 copy of the motion (float32-output flow path)
-    double det[2][kInline][5];      // cx, cy, assoc radius, dyn s-threshold, assoc s-threshold
-    int lab[2][kInline];
-    float4 detf[2][kInline + 1];    // float32 screen: cx, cy, Dlo, Dhi  (+1: the loop reads one ahead)
-    float deta[2][kInline + 1];     // float32 screen: A
+enum : unsigned {
+    kOutXy = 1u << 0, kOutFlow = 1u << 1, kHasDets = 1u << 2, kOutClosest = 1u << 3, kOutCls = 1u << 4,
+    kOutReg = 1u << 5, kOutDyn = 1u << 6, kOutValid = 1u << 7, kOutExcl = 1u << 8, kCanonical = 1u << 9,
+    kKindShift = 10,
+};
+// the headline configuration: displacement flow in the canonical frame, target_cls, target_reg, exclude mask
+constexpr int kCfgHeadline = (int)(kOutFlow | kHasDets | kOutCls | kOutReg | kOutExcl | kCanonical);
+
+struct FlatBatch {
+    const float *ranges;
+    long long sample_stride;
+    void *xy, *flow;
+    int64_t *closest, *target_cls;
+    float *target_reg, *dyn_mask, *valid_mask, *exclude_mask;
+    const int32_t *det_offsets;
+    const double *ws_rec, *ws_det;
+    int B;
+    int wave0;              // first wave-chunk of this batch in the launch
+};
+static_assert(sizeof(FlatBatch) % 8 == 0, "FlatBatch is read from the kernel arguments in 8-byte words");
+
+struct FlatArgs {
+    const double *tab;      // [3N] float64: phi, then (cos, sin) interleaved
+    const float *tabf;      // [N][2] = (float)cos, (float)sin, or nullptr (converted in the kernel)
+    int N, halfN;
+    unsigned magic_m;       // x / halfN = mulhi(x, magic_m) >> magic_s for x < 2^31
+    int magic_s;
+    unsigned flags;         // run-time configuration (CFG < 0)
+    int nb;                 // batches in this launch
+    int total_waves;        // wave-chunks of all batches
+    int main_blocks;        // blocks that stream; blocks behind them run params jobs
+    double ra[3], sd[3], sa[3];
+    int lb[3];
+    float m_dyn;            // max_c (1e-3 + 1e-4 sd_c), rounded up
+    float thr_assoc;        // max_c (sa_c - sd_c + 1e-3 + 1e-4 sd_c), rounded up
+    int wave0[kMaxSlots];   // first wave-chunk of each batch
+    FlatBatch b[kMaxSlots];
+};
+
+struct ParamsMulti {
+    int nb;
+    int blk0[kMaxSlots + 1];   // first params block of each batch (unused slots: the total); blk0[kMaxSlots] = total
+    PreArgs p[kMaxSlots];
 };
 
 template <typename T>
@@ -657,44 +717,105 @@ __device__ __forceinline__ void apply_motion_t(int kind, T px, T py, T m0, T m1,
     }
 }
 
+template <int CFG>
+struct FlatCfg {
+    unsigned rt;
+    __device__ __forceinline__ bool has(unsigned bit) const { return CFG >= 0 ? ((unsigned)CFG & bit) != 0 : (rt & bit) != 0; }
+    __device__ __forceinline__ int kind() const { return CFG >= 0 ? (CFG >> kKindShift) & 7 : (int)(rt >> kKindShift) & 7; }
+};
+
+using D2V = double __attribute__((ext_vector_type(2)));
+
+// what a lane loads for one 128-point run of its wave: issued for all runs BEFORE the record images are staged,
+// so that the wave pays one memory round trip (loads placed behind the LDS hand-off would wait for it)
+struct RunLoads {
+    float2 rv;          // range pair
+    float4 tf;          // float32 (cos, sin) of the two beams (tabf given)
+    D2V t0v, t1v;       // float64 (cos, sin) (float64 kernels, or no tabf)
+    int local, q;
+    bool ok;
+};
+
 template <typename OutT>
-__device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm, const int q, const int b,
-                                           const bool ok, const long long o2, const float2 rv,
-                                           const double2 t0v, const double2 t1v, const double *tab_cs)
+__device__ __forceinline__ RunLoads flat_loads(const FlatArgs &L, const FlatBatch &bt, const int lane, const int sA,
+                                               const int l0)
 {
-    // float32 outputs: the flow is evaluated in float32 (error ~1e-7 m against the float64 reference at 25 m
-    // range; stated bar 1e-5 m in the tests, 1e-4 m in BASELINE.json).  Association, masks and regression
-    // targets are decided on the float64 values exactly as before.
     constexpr bool kF32 = sizeof(OutT) == 4;
-    const bool want_flow = a.flow != nullptr;
-    const bool want_assoc = a.det_offsets != nullptr;
+    RunLoads in;
+    int local = l0 + lane;
+    const int q = local >= L.halfN ? 1 : 0;               // 64 <= halfN: at most one wrap inside a run
+    local -= q ? L.halfN : 0;
+    in.local = local;
+    in.q = q;
+    in.ok = sA + q < bt.B;
+    const unsigned i0 = 2u * (unsigned)local;
+    // range pair: clamped row, unconditional (a load inside `if (ok)` is waited for before the next is issued)
+    const GLOBAL_AS float *rowA = (const GLOBAL_AS float *)bt.ranges + (long long)sA * bt.sample_stride;
+    const unsigned roff = (q && in.ok ? (unsigned)bt.sample_stride : 0u) + i0;
+    const F2V rr = *(const GLOBAL_AS F2V *)(rowA + roff);
+    in.rv = make_float2(rr.x, rr.y);
+    in.tf = make_float4(0.f, 0.f, 0.f, 0.f);
+    in.t0v = D2V{0.0, 0.0};
+    in.t1v = D2V{0.0, 0.0};
+    if (kF32 && L.tabf) {
+        in.tf = *reinterpret_cast<const float4 *>(L.tabf + 2u * i0);
+    } else {
+        const double *tab_cs = L.tab + L.N;
+        in.t0v = *reinterpret_cast<const D2V *>(tab_cs + 2u * i0);
+        in.t1v = *reinterpret_cast<const D2V *>(tab_cs + 2u * i0 + 2);
+    }
+    return in;
+}
+
+// one 128-point run of a wave: pair index o2 (flat, within the batch) = pair0 + lane
+template <typename OutT, int CFG>
+__device__ __forceinline__ void flat_run(const FlatArgs &L, const FlatBatch &bt, const FlatCfg<CFG> cfg,
+                                         const unsigned char *lds, const int lane, const int sA, const int l0,
+                                         const long long pair0, const RunLoads &in)
+{
+    constexpr bool kF32 = sizeof(OutT) == 4;
+    const int halfN = L.halfN, N = L.N;
+    const int local = in.local, q = in.q;
+    const int b = sA + q;
+    const bool ok = in.ok;
+    const int i0 = 2 * local;
+    const float2 rv = in.rv;
+    const double *tab_cs = L.tab + N;
+    float csf[2], snf[2];
+    const D2V t0v = in.t0v, t1v = in.t1v;
+    if (kF32 && L.tabf) {
+        csf[0] = in.tf.x; snf[0] = in.tf.y; csf[1] = in.tf.z; snf[1] = in.tf.w;
+    } else {
+        csf[0] = (float)t0v.x; snf[0] = (float)t0v.y; csf[1] = (float)t1v.x; snf[1] = (float)t1v.y;
+    }
     const float r[2] = {rv.x, rv.y};
-    const float csf[2] = {(float)t0v.x, (float)t1v.x}, snf[2] = {(float)t0v.y, (float)t1v.y};
     F2V pxf = {r[0] * csf[0], r[1] * csf[1]}, pyf = {r[0] * snf[0], r[1] * snf[1]};
     // float64 cos / sin are needed on the rare exact paths only: re-read there (L1 / L2 hits) instead of
-    // holding 8 registers across the whole body (the 64-register budget of 8 waves per SIMD)
-    auto cs64 = [&](int k) { return tab_cs[2 * k]; };
-    auto sn64 = [&](int k) { return tab_cs[2 * k + 1]; };
+    // holding 8 registers across the whole body
+    auto cs64 = [&](int k) { return tab_cs[2u * (unsigned)(i0 + k)]; };
+    auto sn64 = [&](int k) { return tab_cs[2u * (unsigned)(i0 + k) + 1]; };
     auto p64x = [&](int k) { return (double)r[k] * cs64(k); };
     auto p64y = [&](int k) { return (double)r[k] * sn64(k); };
+    const unsigned char *hdr = lds + q * kImgBytes;       // this lane's sample: its flat image
 
-    if (ok && a.xy) {
-        OutT *xy = static_cast<OutT *>(a.xy);
-        store2<OutT>(xy, 2 * o2, p64x(0), p64y(0));
-        store2<OutT>(xy, 2 * o2 + 1, p64x(1), p64y(1));
+    if (cfg.has(kOutXy) && ok) {
+        OutT *xy = static_cast<OutT *>(bt.xy) + 4 * pair0;
+        store2<OutT>(xy, 2u * (unsigned)lane, p64x(0), p64y(0));
+        store2<OutT>(xy, 2u * (unsigned)lane + 1, p64x(1), p64y(1));
     }
 
     // ---- rigid-motion flow ---------------------------------------------------
-    if (want_flow) {
-        if (kF32 && a.flow_kind != 1) {   // kind 1 subtracts the point from its moved image: float64 only
-            const float4 ma = *reinterpret_cast<const float4 *>(&sm.motf[q][0]);
-            const float4 mb = *reinterpret_cast<const float4 *>(&sm.motf[q][4]);
+    if (cfg.has(kOutFlow)) {
+        const int kind = cfg.kind();
+        if (kF32 && kind != 1) {   // kind 1 subtracts the point from its moved image: float64 only
+            const float4 ma = *reinterpret_cast<const float4 *>(hdr);
+            const float4 mb = *reinterpret_cast<const float4 *>(hdr + 16);
             float fxs[2], fys[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 float fx, fy;
-                apply_motion_t<float>(a.flow_kind, pxf[k], pyf[k], ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, fx, fy);
-                if (a.canonical) {
+                apply_motion_t<float>(kind, pxf[k], pyf[k], ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, fx, fy);
+                if (cfg.has(kCanonical)) {
                     const float gx = fmaf(csf[k], fx, -snf[k] * fy);
                     const float gy = fmaf(snf[k], fx, csf[k] * fy);
                     fx = gx;
@@ -703,25 +824,43 @@ __device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm,
                 fxs[k] = fx;
                 fys[k] = fy;
             }
-            if (ok) stream_f4(reinterpret_cast<float *>(a.flow), o2, fxs[0], fys[0], fxs[1], fys[1]);
+            if (ok) stream_f4(reinterpret_cast<float *>(bt.flow) + 4 * pair0, (unsigned)lane, fxs[0], fys[0], fxs[1], fys[1]);
         } else {
             // float64 outputs (and float32 kind 1): the reference's operation order in float64
-            const double m0 = sm.mot[q][0], m1 = sm.mot[q][1], m2 = sm.mot[q][2], m3 = sm.mot[q][3];
-            const double tr0 = sm.mot[q][4], tr1 = sm.mot[q][5], dph = sm.mot[q][6];
-            OutT *fl = static_cast<OutT *>(a.flow);
-            const double cs[2] = {t0v.x, t1v.x}, sn[2] = {t0v.y, t1v.y};
+            const double *mot = reinterpret_cast<const double *>(hdr + kImgMot);
+            const double m0 = mot[0], m1 = mot[1], m2 = mot[2], m3 = mot[3];
+            const double tr0 = mot[4], tr1 = mot[5], dph = mot[6];
+            OutT *fl = static_cast<OutT *>(bt.flow) + 4 * pair0;
+            double cs[2], sn[2];
+            if (kF32 && L.tabf) {
+                cs[0] = cs64(0); sn[0] = sn64(0); cs[1] = cs64(1); sn[1] = sn64(1);
+            } else {
+                cs[0] = t0v.x; sn[0] = t0v.y; cs[1] = t1v.x; sn[1] = t1v.y;
+            }
+            double f[4];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 double fx, fy;
-                apply_motion(a.flow_kind, (double)r[k] * cs[k], (double)r[k] * sn[k], m0, m1, m2, m3, tr0, tr1, dph, fx, fy);
-                if (a.canonical) {
+                apply_motion(kind, (double)r[k] * cs[k], (double)r[k] * sn[k], m0, m1, m2, m3, tr0, tr1, dph, fx, fy);
+                if (cfg.has(kCanonical)) {
                     // einsum('ijk,ik->ij'): c*fx + (-s)*fy ; s*fx + c*fy, no fusion
                     const double gx = cs[k] * fx + (-sn[k]) * fy;
                     const double gy = sn[k] * fx + cs[k] * fy;
                     fx = gx;
                     fy = gy;
                 }
-                if (ok) store2<OutT>(fl, 2 * o2 + k, fx, fy);
+                f[2 * k] = fx;
+                f[2 * k + 1] = fy;
+            }
+            if (ok) {
+                if (kF32) {
+                    stream_f4(reinterpret_cast<float *>(fl), (unsigned)lane, (float)f[0], (float)f[1], (float)f[2], (float)f[3]);
+                } else {
+                    D2V v0 = {f[0], f[1]}, v1 = {f[2], f[3]};
+                    GLOBAL_AS D2V *dst = (GLOBAL_AS D2V *)fl + 2u * (unsigned)lane;
+                    __builtin_nontemporal_store(v0, dst);
+                    __builtin_nontemporal_store(v1, dst + 1);
+                }
             }
         }
     }
@@ -734,86 +873,89 @@ __device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm,
     }
 
     // ---- association + dynamic mask ------------------------------------------
-    if (want_assoc) {
+    if (cfg.has(kHasDets)) {
+        const bool want_assoc = cfg.has(kOutClosest) || cfg.has(kOutCls) || cfg.has(kOutReg);
+        const bool want_dyn = cfg.has(kOutDyn) || cfg.has(kOutExcl);
+        const int4 h1 = *reinterpret_cast<const int4 *>(hdr + 16);      // {t0, t1, dphi, count}
+        const int2 h2 = *reinterpret_cast<const int2 *>(hdr + 32);      // class bytes
+        const int2 h3 = *reinterpret_cast<const int2 *>(hdr + 40);      // far flags
+        const int nd = ok ? h1.w : 0;
+        const int n_in = min(nd, kInline);
+        // uniform trip count: the larger of the two samples' counts; the shorter sample's slots beyond its
+        // count hold the null entry
+        const int nA = l0 < halfN ? reinterpret_cast<const int *>(lds)[7] : 0;
+        const int nB = l0 + 63 >= halfN ? reinterpret_cast<const int *>(lds + kImgBytes)[7] : 0;
+        const int n_loop = __builtin_amdgcn_readfirstlane(min(max(nA, nB), kInline));
+        F2V mind = {INFINITY, INFINITY};
+        const unsigned char *ent = hdr + kImgScreen;
+        for (int j = 0; j < n_loop; ++j) {
+            const float4 e = *reinterpret_cast<const float4 *>(ent + 16 * j);
+            const F2V cx2 = {e.x, e.x}, cy2 = {e.y, e.y}, ns2 = {e.z, e.z};
+            const F2V ex = pxf - cx2, ey = pyf - cy2;
+            F2V d = __builtin_elementwise_fma(ey, ey, ns2);
+            d = __builtin_elementwise_fma(ex, ex, d);
+            mind = __builtin_elementwise_min(mind, d);
+        }
+        const bool samp_far = (h3.x | h3.y) != 0;
+        int bidx[2] = {0, 0};
+        int dfirst = 0;
+        auto cls_of = [&](int j) { return ((j < 4 ? h2.x : h2.y) >> (8 * (j & 3))) & 3; };
+        auto sel3 = [&](const double *v, int c) { return c == 0 ? v[0] : (c == 1 ? v[1] : v[2]); };
         // winner so far: 1-based index; 0 = the prepended zero column.  dist - radius of a candidate is
         // negative, so the first candidate beats the zero column without a square root; only a second
         // candidate of the same point (two overlapping discs: rare) needs the two values, and then the
         // incumbent's are recomputed from its index with the same operations.
-        int bidx[2] = {0, 0};
-        int dfirst = 0;
         auto candidate = [&](int k, int j1, double s2, double ra) {
             if (bidx[k] != 0) {
-                const double *w = (bidx[k] <= kInline) ? &sm.det[q][bidx[k] - 1][0]
-                                                       : a.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
-                const double exd = p64x(k) - w[0], eyd = p64y(k) - w[1];
-                if (!(sqrt(s2) - ra < sqrt(exd * exd + eyd * eyd) - w[2])) return;
+                double wx, wy, wra;
+                if (bidx[k] <= kInline) {
+                    const D2V c = *reinterpret_cast<const D2V *>(hdr + kImgCtr + 16 * (bidx[k] - 1));
+                    wx = c.x; wy = c.y; wra = sel3(L.ra, cls_of(bidx[k] - 1));
+                } else {
+                    const GLOBAL_AS double *w = (const GLOBAL_AS double *)bt.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
+                    wx = w[0]; wy = w[1]; wra = w[2];
+                }
+                const double exd = p64x(k) - wx, eyd = p64y(k) - wy;
+                if (!(sqrt(s2) - ra < sqrt(exd * exd + eyd * eyd) - wra)) return;
             }
             bidx[k] = j1;
         };
-        const int nd = ok ? (int)sm.mot[q][7] : 0;
-        const int n_in = min(nd, kInline);
-        bool far[2], inside[2] = {false, false}, all_out[2] = {true, true};
-#pragma unroll
-        for (int k = 0; k < 2; ++k) far[k] = !(fabsf(pxf[k]) + fabsf(pyf[k]) < 100.0f);   // NaN -> exact
-        float4 fnext = sm.detf[q][0];
-        float anext = sm.deta[q][0];
-        for (int j = 0; j < n_in; ++j) {
-            const float4 f = fnext;
-            const float fa = anext;
-            fnext = sm.detf[q][j + 1];
-            anext = sm.deta[q][j + 1];
-            const F2V cx2 = {f.x, f.x}, cy2 = {f.y, f.y};
-            const F2V ex = pxf - cx2, ey = pyf - cy2;
-            F2V s2f = ey * ey;
-            s2f = __builtin_elementwise_fma(ex, ex, s2f);
-            bool need = false;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                inside[k] |= s2f[k] <= f.z;
-                all_out[k] &= s2f[k] > f.w;
-                need |= (s2f[k] <= fa) || far[k];
-            }
-            if (need) {
-                const double cx = sm.det[q][j][0], cy = sm.det[q][j][1], sa = sm.det[q][j][4];
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (!((s2f[k] <= fa) || far[k])) continue;
-                    const double exd = p64x(k) - cx, eyd = p64y(k) - cy;
-                    const double s2 = exd * exd + eyd * eyd;   // cdist: (dx*dx) + (dy*dy), no fusion
-                    if (s2 <= sa) candidate(k, j + 1, s2, sm.det[q][j][2]);   // dist < assoc radius
-                }
-            }
-        }
-        // dynamic mask: decided by the screen unless a point sits within the error band of a threshold
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (inside[k] && !far[k]) {
-                dmask[k] = 0.0f;
-            } else if (far[k] || !all_out[k]) {
+            const bool exk = samp_far || !(fabsf(pxf[k]) + fabsf(pyf[k]) < 100.0f);   // NaN -> exact
+            bool need_dyn = false;
+            if (!exk && mind[k] <= -L.m_dyn) dmask[k] = 0.0f;
+            else need_dyn = want_dyn && (exk || mind[k] <= L.m_dyn);
+            const bool need_assoc = want_assoc && (exk || mind[k] <= L.thr_assoc);
+            if (need_dyn || need_assoc) {
                 const double pxd = p64x(k), pyd = p64y(k);
                 for (int j = 0; j < n_in; ++j) {
-                    const double exd = pxd - sm.det[q][j][0], eyd = pyd - sm.det[q][j][1];
-                    if (exd * exd + eyd * eyd <= sm.det[q][j][3]) dmask[k] = 0.0f;   // dist <= dyn radius
+                    const D2V c = *reinterpret_cast<const D2V *>(hdr + kImgCtr + 16 * j);
+                    const int cl = cls_of(j);
+                    const double exd = pxd - c.x, eyd = pyd - c.y;
+                    const double s2 = exd * exd + eyd * eyd;   // cdist: (dx*dx) + (dy*dy), no fusion
+                    if (need_dyn && s2 <= sel3(L.sd, cl)) dmask[k] = 0.0f;                 // dist <= dyn radius
+                    if (need_assoc && s2 <= sel3(L.sa, cl)) candidate(k, j + 1, s2, sel3(L.ra, cl));   // dist < assoc radius
                 }
             }
         }
         if (nd > kInline) {
             // crowded sample: detections kInline.. from the CSR table (every lane of the sample reads the
             // same rows: L1 / L2 hits), exact test only
-            dfirst = a.det_offsets[b];
+            dfirst = ((const GLOBAL_AS int32_t *)bt.det_offsets)[b];
             for (int j = kInline; j < nd; ++j) {
-                const double *w = a.ws_det + (long long)(dfirst + j) * kDetStride;
+                const GLOBAL_AS double *w = (const GLOBAL_AS double *)bt.ws_det + (long long)(dfirst + j) * kDetStride;
                 const double cx = w[0], cy = w[1], ra = w[2], sd = w[3], sa = w[5];
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const double exd = p64x(k) - cx, eyd = p64y(k) - cy;
                     const double s2 = exd * exd + eyd * eyd;
                     if (s2 <= sd) dmask[k] = 0.0f;
-                    if (s2 <= sa) candidate(k, j + 1, s2, ra);
+                    if (want_assoc && s2 <= sa) candidate(k, j + 1, s2, ra);
                 }
             }
         }
-        if (ok) {
+        if (ok && want_assoc) {
             long long cls[2];
             float gx[2], gy[2];
 #pragma unroll
@@ -825,11 +967,12 @@ __device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm,
                     // sin(dp-phi)*dr = cy*cos(phi) - cx*sin(phi)
                     double wx, wy;
                     if (bidx[k] <= kInline) {
-                        wx = sm.det[q][bidx[k] - 1][0];
-                        wy = sm.det[q][bidx[k] - 1][1];
-                        cls[k] = sm.lab[q][bidx[k] - 1];
+                        const D2V c = *reinterpret_cast<const D2V *>(hdr + kImgCtr + 16 * (bidx[k] - 1));
+                        wx = c.x; wy = c.y;
+                        const int cl = cls_of(bidx[k] - 1);
+                        cls[k] = cl == 0 ? L.lb[0] : (cl == 1 ? L.lb[1] : L.lb[2]);
                     } else {
-                        const double *w = a.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
+                        const GLOBAL_AS double *w = (const GLOBAL_AS double *)bt.ws_det + (long long)(dfirst + bidx[k] - 1) * kDetStride;
                         wx = w[0];
                         wy = w[1];
                         cls[k] = (long long)w[4];
@@ -839,88 +982,102 @@ __device__ __forceinline__ void flat_chunk(const PreArgs &a, const FlatSmem &sm,
                     gy[k] = (float)((wx * c + wy * sn_) - (double)r[k]);
                 }
             }
-            if (a.closest) stream_ll2(reinterpret_cast<long long *>(a.closest), o2, bidx[0], bidx[1]);
-            if (a.target_cls) stream_ll2(reinterpret_cast<long long *>(a.target_cls), o2, cls[0], cls[1]);
-            if (a.target_reg) stream_f4(a.target_reg, o2, gx[0], gy[0], gx[1], gy[1]);
+            if (cfg.has(kOutClosest)) stream_ll2(reinterpret_cast<long long *>(bt.closest) + 2 * pair0, (unsigned)lane, bidx[0], bidx[1]);
+            if (cfg.has(kOutCls)) stream_ll2(reinterpret_cast<long long *>(bt.target_cls) + 2 * pair0, (unsigned)lane, cls[0], cls[1]);
+            if (cfg.has(kOutReg)) stream_f4(bt.target_reg + 4 * pair0, (unsigned)lane, gx[0], gy[0], gx[1], gy[1]);
         }
     }
 
     if (ok) {
-        if (a.dyn_mask) stream_f2(a.dyn_mask, o2, dmask[0], dmask[1]);
-        if (a.valid_mask) stream_f2(a.valid_mask, o2, vmask[0], vmask[1]);
-        if (a.exclude_mask) stream_f2(a.exclude_mask, o2, dmask[0] * vmask[0], dmask[1] * vmask[1]);
+        if (cfg.has(kOutDyn)) stream_f2(bt.dyn_mask + 2 * pair0, (unsigned)lane, dmask[0], dmask[1]);
+        if (cfg.has(kOutValid)) stream_f2(bt.valid_mask + 2 * pair0, (unsigned)lane, vmask[0], vmask[1]);
+        if (cfg.has(kOutExcl)) stream_f2(bt.exclude_mask + 2 * pair0, (unsigned)lane, dmask[0] * vmask[0], dmask[1] * vmask[1]);
     }
 }
 
-template <typename OutT>
-__device__ __forceinline__ void scan_flat(const PreArgs &a, const int phase, const int row, const int period,
-                                          const float inv_half_n)
+// grid = main_blocks (THREADS / 64 wave-chunks each, CPW runs of 128 points per wave-chunk) + the blocks that
+// run the params jobs of the NEXT batches (chained form; params blocks last: dispatched first, their long
+// sincos chains would hold the slots the streaming waves need)
+// A slot of an array inside the kernel arguments, chosen at run time: indexing the by-value argument itself makes
+// the compiler copy the whole array to scratch; reading the slot's words through the kernarg segment pointer
+// (constant address space, uniform offset) is a handful of scalar loads.
+typedef const __attribute__((address_space(4))) unsigned char *kernarg_ptr;
+template <typename S>
+__device__ __forceinline__ S kernarg_struct(kernarg_ptr p)
 {
-    __shared__ FlatSmem sm;
-
-    const int tid = threadIdx.x;
-    const int N = a.N, halfN = N >> 1;
-    // chunk = phase + period * row.  period * 256 points are a whole number of samples (sstep), so the sample
-    // and the point-in-scan index come from the phase alone -- no wide division: x < 2^24 is exact in float32
-    const unsigned x = (unsigned)phase * kFlatThreads;            // pairs since the row's first sample
-    unsigned sp = (unsigned)((float)x * inv_half_n);
-    if (sp * (unsigned)halfN > x) --sp;
-    else if ((sp + 1) * (unsigned)halfN <= x) ++sp;
-    const int sstep = period * kFlatThreads / halfN;              // samples per row of chunks
-    const int sA = row * sstep + (int)sp;                         // workgroup-uniform
-    int local = (int)(x - sp * (unsigned)halfN) + tid;
-    const int q = local >= halfN ? 1 : 0;                         // kFlatThreads <= halfN: at most one wrap
-    local -= q ? halfN : 0;
-    const int i0 = 2 * local;
-    const int b = sA + q;
-    const bool ok = b < a.B;
-    const long long o2 = (long long)b * halfN + local;            // flat pair index: point o = 2 * o2
-
-    // ---- issue every load first ---------------------------------------------
-    // unconditional (clamped) load: a load inside `if (ok)` makes the compiler wait for it at the end of the
-    // branch, i.e. BEFORE the table and record loads are even issued -- two memory round trips instead of one
-    const float2 rv = *reinterpret_cast<const float2 *>(a.ranges + (long long)min(b, a.B - 1) * a.sample_stride + i0);
-    const double2 t0v = *reinterpret_cast<const double2 *>(a.tab + N + 2 * i0);
-    const double2 t1v = *reinterpret_cast<const double2 *>(a.tab + N + 2 * i0 + 2);
-    if (a.flow != nullptr || a.det_offsets != nullptr) {
-        // records -> LDS: a pure copy (the float32 motion and the detection screens were written by the
-        // params job that produced the record)
-        if (tid < 16) {
-            const int sq = tid >> 3, c = tid & 7;
-            const int bs = min(sA + sq, a.B - 1);
-            const double *rec = a.ws_rec + (long long)bs * kRecStride;
-            sm.mot[sq][c] = rec[c];
-            sm.motf[sq][c] = reinterpret_cast<const float *>(rec + kRecF32Mot)[c];
-        } else if (a.det_offsets != nullptr && tid < 16 + 2 * kInline) {
-            const int w_ = tid - 16, sq = w_ / kInline, d = w_ - sq * kInline;
-            const int bs = min(sA + sq, a.B - 1);
-            const double *rec = a.ws_rec + (long long)bs * kRecStride;
-            const double *w = rec + 8 + d * kDetStride;
-            const float *f = reinterpret_cast<const float *>(rec + kRecF32Det) + d * 6;
-            sm.det[sq][d][0] = w[0];
-            sm.det[sq][d][1] = w[1];
-            sm.det[sq][d][2] = w[2];
-            sm.det[sq][d][3] = w[3];
-            sm.det[sq][d][4] = w[5];
-            sm.lab[sq][d] = (int)w[4];
-            sm.detf[sq][d] = make_float4(f[0], f[1], f[2], f[3]);
-            sm.deta[sq][d] = f[4];
-        }
-        __syncthreads();
-    }
-    flat_chunk<OutT>(a, sm, q, b, ok, o2, rv, t0v, t1v, a.tab + N + 2 * i0);
+    static_assert(sizeof(S) % 8 == 0, "kernarg slots are read in 8-byte words");
+    S out;
+    unsigned long long *w = reinterpret_cast<unsigned long long *>(&out);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(S) / 8); ++i)
+        w[i] = *reinterpret_cast<const __attribute__((address_space(4))) unsigned long long *>(p + 8 * i);
+    return out;
 }
+constexpr size_t kFlatArgsKernargBytes = (sizeof(FlatArgs) + 7) & ~(size_t)7;   // offset of the second argument
 
-// grid (period, rows + extra): rows [0, main_rows) stream the current batch, the rest run the params jobs of
-// the NEXT batch (chained form; params rows last, see scan_preprocess_chain_kernel)
-template <typename OutT>
-__global__ __launch_bounds__(kFlatThreads, 8) void scan_flat_kernel(PreArgs a, PreArgs nx, int main_rows, float inv_half_n)
+template <typename OutT, int CFG, int THREADS, int CPW>
+__global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L, const ParamsMulti P)
 {
-    if ((int)blockIdx.y >= main_rows) {
-        params_work(nx, (((int)blockIdx.y - main_rows) * (int)gridDim.x + (int)blockIdx.x) * kFlatThreads + threadIdx.x);
+    constexpr int WAVES = THREADS / 64;
+    __shared__ __align__(16) unsigned char smem[WAVES][kWaveLds];
+    kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    if ((int)blockIdx.x >= L.main_blocks) {
+        // params blocks: a block belongs to ONE batch (uniform slot index -> scalar loads of its arguments)
+        const int blk = (int)blockIdx.x - L.main_blocks;
+        int k = 0;
+#pragma unroll
+        for (int i = 1; i < kMaxSlots; ++i) k += (blk >= P.blk0[i]) ? 1 : 0;
+        k = __builtin_amdgcn_readfirstlane(k);
+        int b0 = P.blk0[0];
+#pragma unroll
+        for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
+        const auto *pa = reinterpret_cast<const __attribute__((address_space(4))) PreArgs *>(
+            ka + kFlatArgsKernargBytes + offsetof(ParamsMulti, p) + (size_t)k * sizeof(PreArgs));
+        params_work(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
         return;
     }
-    scan_flat<OutT>(a, blockIdx.x, blockIdx.y, gridDim.x, inv_half_n);
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int lane = (int)threadIdx.x & 63;
+    const int w = (int)blockIdx.x * WAVES + wv;
+    if (w >= L.total_waves) return;
+    // batch of this wave-chunk: wave0[i] of the unused slots is INT_MAX
+    int k = 0;
+#pragma unroll
+    for (int i = 1; i < kMaxSlots; ++i) k += (w >= L.wave0[i]) ? 1 : 0;
+    const FlatBatch bt = kernarg_struct<FlatBatch>(ka + offsetof(FlatArgs, b) + (size_t)k * sizeof(FlatBatch));
+    const FlatCfg<CFG> cfg{L.flags};
+    unsigned char *lds = smem[wv];
+
+    // pairs [p0, p0 + 64 * CPW) of the batch's flat pair axis
+    const unsigned p0 = (unsigned)(w - bt.wave0) * (64u * CPW);
+    const int sA = (int)(__umulhi(p0, L.magic_m) >> L.magic_s);      // p0 / halfN
+    const int l0 = (int)(p0 - (unsigned)sA * (unsigned)L.halfN);
+
+    // run c starts 64 * c pairs further; addressed relative to sA (a run that begins in sA + 1 already has q = 1
+    // in every lane; it cannot reach sA + 2: N >= 128 * CPW)
+    RunLoads in[CPW];
+#pragma unroll
+    for (int c = 0; c < CPW; ++c) in[c] = flat_loads<OutT>(L, bt, lane, sA, l0 + 64 * c);
+
+    if (cfg.has(kOutFlow) || cfg.has(kHasDets)) {
+        // flat images of samples sA and sA + 1 -> this wave's LDS slice, a plain copy of 2 x 384 contiguous
+        // bytes: lanes 0..23 sample sA, lanes 32..55 sample sA + 1, 16 bytes each
+        {
+            const int sq = lane >> 5, i = lane & 31;
+            if (i < kImgBytes / 16) {
+                const double *rec = bt.ws_rec + (long long)min(sA + sq, bt.B - 1) * kRecStride;
+                *reinterpret_cast<F4V *>(lds + sq * kImgBytes + 16 * i) = ((const GLOBAL_AS F4V *)(rec + kRecImg))[i];
+            }
+        }
+        // same-wave LDS hand-off: the hardware keeps a wave's LDS operations in order; the fences keep the
+        // compiler from moving the reads above the writes
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+#pragma unroll
+    for (int c = 0; c < CPW; ++c)
+        flat_run<OutT, CFG>(L, bt, cfg, lds, lane, sA, l0 + 64 * c, (long long)p0 + 64 * c, in[c]);
 }
 
 // ---- A4 stand-alone rotation ------------------------------------------------
@@ -989,7 +1146,7 @@ __global__ __launch_bounds__(kThreads, 8) void scan_preprocess_chain_kernel(PreA
     // params rows LAST: measured 20.2 us per step against 22.7 us with the params rows first
     // (dispatched first, their long sincos chains hold CU slots the streaming rows need)
     if ((int)blockIdx.y >= main_rows) {
-        if (blockIdx.x == 0) params_work(nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
+        if (blockIdx.x == 0) params_work(&nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
         return;
     }
     scan_main<OutT, PTS, SPB>(a, blockIdx.y);
@@ -1131,6 +1288,169 @@ void bind_workspace(PreArgs &a, void *workspace, int B)
     a.ws_det = a.ws_rec + (size_t)B * kRecStride;
 }
 
+float f32_round_up(double v)
+{
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafter(f, INFINITY);
+    return f;
+}
+
+// tuning knobs of the flat kernel (threads per workgroup, 128-point runs per wave), POF_FLAT_TUNE="threads,cpw"
+void flat_tuning(int *threads, int *cpw)
+{
+    static int t = 0, c = 0;
+    if (t == 0) {
+        int tt = 128, cc = 1;
+        if (const char *e = std::getenv("POF_FLAT_TUNE")) {
+            int a = 0, b = 0;
+            if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 1 || b == 2)) {
+                tt = a;
+                cc = b;
+            }
+        }
+        c = cc;
+        t = tt;
+    }
+    *threads = t;
+    *cpw = c;
+}
+
+struct FlatCommon {
+    const double *tab;
+    const float *tabf;
+    int N, flow_kind, canonical, out_f64;
+    const double *assoc_radius, *dyn_radius;
+    const int32_t *labels;
+};
+
+// can the flat kernel take this shape?  (pairs of beams per lane, a wave's points within two samples)
+bool flat_shape_ok(int N, int cpw) { return N % 2 == 0 && N >= 128 * cpw; }
+
+unsigned flat_flags(const FlatBatch &b, const FlatCommon &c)
+{
+    unsigned f = 0;
+    if (b.xy) f |= kOutXy;
+    if (b.flow) f |= kOutFlow;
+    if (b.det_offsets) f |= kHasDets;
+    if (b.closest) f |= kOutClosest;
+    if (b.target_cls) f |= kOutCls;
+    if (b.target_reg) f |= kOutReg;
+    if (b.dyn_mask) f |= kOutDyn;
+    if (b.valid_mask) f |= kOutValid;
+    if (b.exclude_mask) f |= kOutExcl;
+    if (c.canonical) f |= kCanonical;
+    f |= (unsigned)c.flow_kind << kKindShift;
+    return f;
+}
+
+template <typename OutT, int CFG>
+void flat_dispatch(int threads, int cpw, dim3 grid, hipStream_t s, const FlatArgs &L, const ParamsMulti &P)
+{
+#define POF_FLAT_CASE(T, C) \
+    if (threads == T && cpw == C) { scan_flat_kernel<OutT, CFG, T, C><<<grid, T, 0, s>>>(L, P); return; }
+    POF_FLAT_CASE(64, 1)
+    POF_FLAT_CASE(64, 2)
+    POF_FLAT_CASE(128, 1)
+    POF_FLAT_CASE(128, 2)
+    POF_FLAT_CASE(256, 1)
+    POF_FLAT_CASE(256, 2)
+#undef POF_FLAT_CASE
+}
+
+// fill the params job set of one "next" batch; returns a status
+int bind_next(const pof_scan_inputs *next, PreArgs &nx, int *jobs)
+{
+    *jobs = 0;
+    if (next->B < 0 || next->D < 0 || next->B > 65535) return POF_E_BADARG;
+    if (next->want_flow && (!next->odom0 || !next->odom1)) return POF_E_BADARG;
+    if (next->flow_kind < 0 || next->flow_kind > 4) return POF_E_BADARG;
+    if (next->det_offsets && next->D > 0 && (!next->det_rphi || !next->det_cls)) return POF_E_BADARG;
+    if (next->B > 0 && (next->want_flow || next->det_offsets)) {
+        if (!next->workspace ||
+            next->workspace_bytes < pof_scan_preprocess_workspace_bytes(next->B, next->det_offsets ? next->D : 0))
+            return POF_E_WORKSPACE;
+        nx.B = next->B; nx.D = next->det_offsets ? next->D : 0;
+        nx.odom0 = next->odom0; nx.odom1 = next->odom1; nx.flow_kind = next->flow_kind;
+        nx.flow = next->want_flow ? reinterpret_cast<void *>(1) : nullptr;  // only tested against null
+        nx.det_offsets = next->det_offsets; nx.det_rphi = next->det_rphi; nx.det_cls = next->det_cls;
+        fill_class_constants(nx, next->det_offsets != nullptr, next->assoc_radius, next->labels, next->dyn_radius);
+        bind_workspace(nx, next->workspace, next->B);
+        *jobs = params_job_count(nx.B, nx.det_offsets != nullptr);
+    }
+    return POF_OK;
+}
+
+// One launch: stream n_cur batches (same N, same set of outputs) and evaluate the params of n_next batches.
+int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_scan_inputs *const *next, int n_next,
+                hipStream_t s)
+{
+    int threads, cpw;
+    flat_tuning(&threads, &cpw);
+    if (!flat_shape_ok(c.N, cpw)) cpw = 1;
+    FlatArgs L = {};
+    L.tab = c.tab; L.tabf = c.tabf; L.N = c.N; L.halfN = c.N / 2;
+    int lg = 0;
+    while ((1u << lg) < (unsigned)L.halfN) ++lg;
+    L.magic_m = (unsigned)(((1ull << (31 + lg)) + (unsigned)L.halfN - 1) / (unsigned)L.halfN);
+    L.magic_s = lg - 1;
+    L.flags = flat_flags(cur[0], c);
+    L.nb = n_cur;
+    PreArgs cc = {};
+    fill_class_constants(cc, cur[0].det_offsets != nullptr, c.assoc_radius, c.labels, c.dyn_radius);
+    L.ra[0] = cc.ra0; L.ra[1] = cc.ra1; L.ra[2] = cc.ra2;
+    L.sd[0] = cc.sd0; L.sd[1] = cc.sd1; L.sd[2] = cc.sd2;
+    L.sa[0] = cc.sa0; L.sa[1] = cc.sa1; L.sa[2] = cc.sa2;
+    L.lb[0] = cc.lb0; L.lb[1] = cc.lb1; L.lb[2] = cc.lb2;
+    double md = 0.0, ta = -HUGE_VAL;
+    for (int k = 0; k < 3; ++k) {
+        const double m = 1e-3 + 1e-4 * std::fmax(L.sd[k], 0.0);
+        md = std::fmax(md, m);
+        ta = std::fmax(ta, L.sa[k] - L.sd[k] + m);
+    }
+    L.m_dyn = f32_round_up(md * (1.0 + 1e-6));
+    L.thr_assoc = f32_round_up(ta + 1e-6 * std::fabs(ta));
+    long long waves = 0;
+    const long long pairs_per_wave = 64LL * cpw;
+    for (int i = 0; i < n_cur; ++i) {
+        if (flat_flags(cur[i], c) != L.flags) return POF_E_BADARG;   // one configuration per launch
+        L.b[i] = cur[i];
+        L.b[i].wave0 = (int)waves;
+        L.wave0[i] = (int)waves;
+        waves += ((long long)cur[i].B * L.halfN + pairs_per_wave - 1) / pairs_per_wave;
+        if ((long long)cur[i].B * L.halfN >= (1LL << 31) || waves >= (1LL << 30)) return POF_E_SHAPE;
+    }
+    for (int i = n_cur; i < kMaxSlots; ++i) L.wave0[i] = 0x7fffffff;
+    L.total_waves = (int)waves;
+    const int wpb = threads / 64;
+    L.main_blocks = (int)((waves + wpb - 1) / wpb);
+    ParamsMulti P = {};
+    P.nb = 0;
+    int extra = 0;
+    for (int i = 0; i < n_next; ++i) {
+        PreArgs nx = {};
+        int jobs = 0;
+        const int rc = bind_next(next[i], nx, &jobs);
+        if (rc != POF_OK) return rc;
+        if (jobs == 0) continue;
+        P.blk0[P.nb] = extra;
+        P.p[P.nb] = nx;
+        extra += (jobs + threads - 1) / threads;
+        ++P.nb;
+    }
+    for (int i = P.nb; i <= kMaxSlots; ++i) P.blk0[i] = extra;
+    if (L.main_blocks + extra == 0) return POF_OK;
+    dim3 grid((unsigned)(L.main_blocks + extra));
+    const bool headline = (L.flags == (unsigned)kCfgHeadline);
+    if (c.out_f64) {
+        if (headline) flat_dispatch<double, kCfgHeadline>(threads, cpw, grid, s, L, P);
+        else flat_dispatch<double, -1>(threads, cpw, grid, s, L, P);
+    } else {
+        if (headline) flat_dispatch<float, kCfgHeadline>(threads, cpw, grid, s, L, P);
+        else flat_dispatch<float, -1>(threads, cpw, grid, s, L, P);
+    }
+    return POF_OK;
+}
+
 int launch_preprocess(const float *ranges, long long sample_stride, int B, int N, const double *tab,
                       const double *odom0, const double *odom1, int flow_kind, int canonical, int out_f64,
                       void *xy, void *flow, const int32_t *det_offsets, const double *det_rphi,
@@ -1172,22 +1492,8 @@ int launch_preprocess(const float *ranges, long long sample_stride, int B, int N
     PreArgs nx = a;
     int next_jobs = 0;
     if (next) {
-        if (next->B < 0 || next->D < 0 || next->B > 65535) return POF_E_BADARG;
-        if (next->want_flow && (!next->odom0 || !next->odom1)) return POF_E_BADARG;
-        if (next->flow_kind < 0 || next->flow_kind > 4) return POF_E_BADARG;
-        if (next->det_offsets && next->D > 0 && (!next->det_rphi || !next->det_cls)) return POF_E_BADARG;
-        if (next->B > 0 && (next->want_flow || next->det_offsets)) {
-            if (!next->workspace ||
-                next->workspace_bytes < pof_scan_preprocess_workspace_bytes(next->B, next->det_offsets ? next->D : 0))
-                return POF_E_WORKSPACE;
-            nx.B = next->B; nx.D = next->det_offsets ? next->D : 0;
-            nx.odom0 = next->odom0; nx.odom1 = next->odom1; nx.flow_kind = next->flow_kind;
-            nx.flow = next->want_flow ? reinterpret_cast<void *>(1) : nullptr;  // only tested against null
-            nx.det_offsets = next->det_offsets; nx.det_rphi = next->det_rphi; nx.det_cls = next->det_cls;
-            fill_class_constants(nx, next->det_offsets != nullptr, next->assoc_radius, next->labels, next->dyn_radius);
-            bind_workspace(nx, next->workspace, next->B);
-            next_jobs = params_job_count(nx.B, nx.det_offsets != nullptr);
-        }
+        const int rc = bind_next(next, nx, &next_jobs);
+        if (rc != POF_OK) return rc;
     }
 
     // float2 row loads need 8-byte aligned rows, 16-byte stores aligned outputs
@@ -1195,21 +1501,18 @@ int launch_preprocess(const float *ranges, long long sample_stride, int B, int N
     const bool vec2 = (N % 2 == 0) && (sample_stride % 2 == 0) && ((reinterpret_cast<uintptr_t>(ranges) & 7) == 0) &&
                       al16(xy) && al16(flow) && al16(closest) && al16(target_cls) && al16(target_reg) &&
                       al16(dyn_mask) && al16(valid_mask) && al16(exclude_mask);
-    // One sample per workgroup.  (Two samples per workgroup share the table loads and were
-    // faster with ordinary stores; with streaming stores one is: 15.4 vs 17.9 us per step.)
     bool chained = false;
-    const long long flat_chunks = ((long long)B * (N / 2) + kFlatThreads - 1) / kFlatThreads;
-    int g = N, h = 2 * kFlatThreads;
-    while (h) { const int t = g % h; g = h; h = t; }
-    const int period = N / g;                                        // chunks after which the point phases repeat
-    const long long rows = (flat_chunks + period - 1) / period;
-    const int extra_rows = (int)(((long long)next_jobs + (long long)period * kFlatThreads - 1) / ((long long)period * kFlatThreads));
-    if (vec2 && N >= 2 * kFlatThreads && (long long)period * kFlatThreads < (1 << 24) && rows + extra_rows <= 65535) {
-        // flat form: line-aligned output chunks per workgroup (see scan_flat)
-        dim3 grid(period, (unsigned)(rows + extra_rows));
-        const float inv = 1.0f / (float)(N / 2);
-        if (out_f64) scan_flat_kernel<double><<<grid, kFlatThreads, 0, s>>>(a, nx, (int)rows, inv);
-        else scan_flat_kernel<float><<<grid, kFlatThreads, 0, s>>>(a, nx, (int)rows, inv);
+    if (vec2 && flat_shape_ok(N, 1) && (long long)B * (N / 2) < (1LL << 31)) {
+        // flat form: line-aligned output runs per wave (see scan_flat_kernel)
+        FlatBatch fb = {};
+        fb.ranges = ranges; fb.sample_stride = sample_stride; fb.xy = xy; fb.flow = flow;
+        fb.closest = closest; fb.target_cls = target_cls; fb.target_reg = target_reg;
+        fb.dyn_mask = dyn_mask; fb.valid_mask = valid_mask; fb.exclude_mask = exclude_mask;
+        fb.det_offsets = det_offsets; fb.ws_rec = a.ws_rec; fb.ws_det = a.ws_det; fb.B = B;
+        FlatCommon fc = {tab, nullptr, N, flow_kind, canonical, out_f64, assoc_radius, dyn_radius, labels};
+        const pof_scan_inputs *nl[1] = {next};
+        const int rc = launch_flat(&fb, 1, fc, nl, (next && next_jobs > 0) ? 1 : 0, s);
+        if (rc != POF_OK) return rc;
         chained = true;
     } else if (vec2) {
         dim3 grid((N / 2 + kThreads - 1) / kThreads, B);
@@ -1272,6 +1575,65 @@ extern "C" int pof_scan_preprocess_chained(const float *ranges, long long sample
                              det_offsets, det_rphi, det_cls, D, assoc_radius, labels, dyn_radius, closest,
                              target_cls, target_reg, dyn_mask, valid_mask, exclude_mask, workspace,
                              workspace_bytes, 2, next, stream);
+}
+
+extern "C" int pof_scan_preprocess_multi(const pof_scan_batch *cur, int n_cur, const pof_scan_inputs *next,
+                                         int n_next, int N, const double *tab, const float *tab_cs_f32,
+                                         int flow_kind, int canonical, int out_f64, const double *assoc_radius,
+                                         const int32_t *labels, const double *dyn_radius, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (n_cur < 0 || n_next < 0 || n_cur > POF_SCAN_MAX_SLOTS || n_next > POF_SCAN_MAX_SLOTS) return POF_E_BADARG;
+    if (n_cur + n_next == 0) return POF_E_BADARG;
+    if ((n_cur > 0 && !cur) || (n_next > 0 && !next)) return POF_E_BADARG;
+    if (n_cur > 0 && (!tab || N < 1)) return POF_E_BADARG;
+    if (flow_kind < 0 || flow_kind > 4) return POF_E_BADARG;
+    if (n_cur > 0 && !flat_shape_ok(N, 1)) return POF_E_SHAPE;   // odd or short scans: pof_scan_preprocess_chained
+    FlatBatch fb[kMaxSlots] = {};
+    for (int i = 0; i < n_cur; ++i) {
+        const pof_scan_batch &c = cur[i];
+        if (!c.ranges || c.B < 0 || c.D < 0) return POF_E_BADARG;
+        if (c.det_offsets && (!assoc_radius || !labels || !dyn_radius)) return POF_E_BADARG;
+        if (c.sample_stride < N || (c.sample_stride & 1)) return POF_E_SHAPE;
+        auto al = [](const void *q, uintptr_t m) { return (reinterpret_cast<uintptr_t>(q) & m) == 0; };
+        if (!al(c.ranges, 7) || !al(c.xy, 15) || !al(c.flow, 15) || !al(c.closest, 15) || !al(c.target_cls, 15) ||
+            !al(c.target_reg, 15) || !al(c.dyn_mask, 15) || !al(c.valid_mask, 15) || !al(c.exclude_mask, 15))
+            return POF_E_SHAPE;
+        const bool need_ws = c.flow || c.det_offsets;
+        if (need_ws && (!c.workspace || c.workspace_bytes < pof_scan_preprocess_workspace_bytes(c.B, c.det_offsets ? c.D : 0)))
+            return POF_E_WORKSPACE;
+        PreArgs w = {};
+        bind_workspace(w, c.workspace, c.B);
+        fb[i].ranges = c.ranges; fb[i].sample_stride = c.sample_stride; fb[i].xy = c.xy; fb[i].flow = c.flow;
+        fb[i].closest = c.closest; fb[i].target_cls = c.target_cls; fb[i].target_reg = c.target_reg;
+        fb[i].dyn_mask = c.dyn_mask; fb[i].valid_mask = c.valid_mask; fb[i].exclude_mask = c.exclude_mask;
+        fb[i].det_offsets = c.det_offsets; fb[i].ws_rec = w.ws_rec; fb[i].ws_det = w.ws_det; fb[i].B = c.B;
+    }
+    // empty batches stream nothing
+    int n_live = 0;
+    for (int i = 0; i < n_cur; ++i)
+        if (fb[i].B > 0) fb[n_live++] = fb[i];
+    const pof_scan_inputs *nl[kMaxSlots] = {};
+    for (int i = 0; i < n_next; ++i) nl[i] = next + i;
+    FlatCommon fc = {tab, tab_cs_f32, N, flow_kind, canonical, out_f64, assoc_radius, dyn_radius, labels};
+    if (n_live == 0) {
+        // params only: a plain params launch per batch
+        for (int i = 0; i < n_next; ++i) {
+            PreArgs nx = {};
+            int jobs = 0;
+            const int rc = bind_next(nl[i], nx, &jobs);
+            if (rc != POF_OK) return rc;
+            if (jobs > 0) {
+                scan_params_kernel<<<(jobs + 255) / 256, 256, 0, pof_stream(stream)>>>(nx);
+                POF_CHECK_LAUNCH();
+            }
+        }
+        return POF_OK;
+    }
+    const int rc = launch_flat(fb, n_live, fc, nl, n_next, pof_stream(stream));
+    if (rc != POF_OK) return rc;
+    POF_CHECK_LAUNCH();
+    return POF_OK;
 }
 
 extern "C" int pof_scan_preprocess(const float *ranges, long long sample_stride, int B, int N,

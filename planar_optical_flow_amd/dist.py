@@ -27,6 +27,10 @@ def world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def backend():
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
 def init_distributed(backend=None):
     """Initialise from the torchrun environment (RANK / WORLD_SIZE / LOCAL_RANK /
     MASTER_ADDR / MASTER_PORT).  Returns (rank, world, device)."""
@@ -57,47 +61,97 @@ def shard_range(n, r=None, w=None):
 
 
 class GradientAllReduce:
-    """Averages the gradients of `model` over all ranks through ONE flat bucket.
+    """Averages the gradients of `model` over all ranks through ONE flat bucket -- without packing.
 
-    The bucket is allocated once; ``__call__`` packs the .grad tensors, issues a
-    single all-reduce(sum), scales by 1/world and unpacks.  Parameters without a
-    gradient (frozen / unused, e.g. the duplicate conv1..conv4 of the box head)
-    contribute zeros so every rank reduces the same layout."""
+    Every ``p.grad`` IS a view into the bucket (set here, kept by ``zero_grad(set_to_none=False)``; autograd
+    accumulates into an existing gradient in place), so ``__call__`` is the collective alone: one all-reduce, no
+    per-parameter copies, no host synchronisation -- and capturable in a hipGraph together with the step around it
+    (RCCL collectives are stream-ordered; ``graph_step.GraphedTrainStep``).  A gradient that was dropped or
+    replaced since (``zero_grad(set_to_none=True)``, ``p.grad = None``) is copied back into its slice and
+    re-pointed on the next call, so correctness never depends on the caller's zero_grad flavour.  Parameters the
+    loss does not reach (the duplicate conv1..conv4 of the box head) hold zeros, so every rank reduces the same
+    layout.
 
-    def __init__(self, model):
+    The bucket's LAST element is the agreed stop flag of the training loop (``set_stop`` / ``stop_requested``): it
+    rides in the same all-reduce, and is read back one step later through a pinned host word and an event, i.e.
+    without a blocking device-to-host copy in the step."""
+
+    def __init__(self, model, always=False):
+        self.always = bool(always)       # run the collective in a one-rank group too (RCCL smoke / capture tests)
         self.params = [p for p in model.parameters() if p.requires_grad]
         n = sum(p.numel() for p in self.params)
         dev = self.params[0].device if self.params else torch.device("cpu")
-        self.bucket = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.bucket = torch.zeros(n + 1, dtype=torch.float32, device=dev)
+        self.views = []
+        off = 0
+        for p in self.params:
+            k = p.numel()
+            self.views.append(self.bucket[off:off + k].view(p.shape))
+            off += k
+        self.flag = self.bucket[n:n + 1]
+        self._host_flag = None
+        self._flag_event = None
+        self._pending = False
+        self.attach()
+
+    def attach(self):
+        """Point every parameter's gradient at its slice of the bucket (keeping what it holds)."""
+        with torch.no_grad():
+            for p, v in zip(self.params, self.views):
+                if p.grad is None:
+                    v.zero_()
+                elif p.grad.data_ptr() != v.data_ptr():
+                    v.copy_(p.grad)
+                p.grad = v
+        return self
+
+    def set_stop(self, stop):
+        """This rank's stop request for the coming all-reduce (no synchronisation: a fill)."""
+        self.flag.fill_(1.0 if stop else 0.0)
+
+    def stop_requested(self):
+        """True once ANY rank had asked to stop at the previous reduced step (the same answer on every rank)."""
+        if not self._pending:
+            return False
+        if self._flag_event is not None:
+            self._flag_event.synchronize()          # recorded a whole step ago: normally already complete
+        return bool(self._host_flag[0] > 0)
+
+    def _publish_flag(self):
+        if self.bucket.is_cuda:
+            if self._host_flag is None:
+                self._host_flag = torch.zeros(1, dtype=torch.float32).pin_memory()
+                self._flag_event = torch.cuda.Event()
+            self._host_flag.copy_(self.flag, non_blocking=True)
+            self._flag_event.record()
+        else:
+            self._host_flag = self.flag.clone()
+        self._pending = True
+
+    def reduce_(self):
+        """The collective alone (what a captured step holds): bucket <- mean over ranks."""
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
+            self.bucket.mul_(1.0 / world_size())
 
     def __call__(self, force=False):
         """force=True also runs the (then trivial) collective in a one-rank group: the world-size-1 RCCL smoke
         test drives the device path that way."""
-        if not (is_distributed() or (force and dist.is_available() and dist.is_initialized())):
+        if not (is_distributed() or ((force or self.always) and dist.is_available() and dist.is_initialized())):
             return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.bucket[off:off + n].zero_()
-            else:
-                self.bucket[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM)
-        self.bucket.mul_(1.0 / world_size())
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = self.bucket[off:off + n].reshape(p.shape).clone()
-            else:
-                p.grad.copy_(self.bucket[off:off + n].reshape(p.shape))
-            off += n
+        if any(p.grad is None or p.grad.data_ptr() != v.data_ptr() for p, v in zip(self.params, self.views)):
+            self.attach()
+        self.reduce_()
+        if not (self.bucket.is_cuda and torch.cuda.is_current_stream_capturing()):
+            self._publish_flag()
 
 
 def any_rank(flag, device=None):
     """True on every rank as soon as `flag` is true on one: the stop flag of the training loop (a SIGTERM may
-    reach only some ranks; without agreement the others would block in the next gradient all-reduce)."""
+    reach only some ranks; without agreement the others would block in the next gradient all-reduce).  A blocking
+    form for callers without a gradient bucket; the training loop uses the bucket's flag element instead."""
     if not is_distributed():
         return bool(flag)
     use_dev = device if (device is not None and dist.get_backend() == "nccl") else torch.device("cpu")
@@ -131,13 +185,12 @@ class _SyncBatchNormFn(torch.autograd.Function):
                 running_var.mul_(1 - momentum).add_(momentum * (var * n / torch.clamp(n - 1, min=1.0)).to(running_var.dtype))
         shape = [1, C] + [1] * (x.dim() - 2)
         xhat = ((xd - mean.view(shape)) * invstd.view(shape)).to(x.dtype)
-        ctx.save_for_backward(xhat, weight, invstd.to(x.dtype))
-        ctx.n = float(n.item())
+        ctx.save_for_backward(xhat, weight, invstd.to(x.dtype), n)     # n stays on the device: no host sync
         return xhat * weight.view(shape) + bias.view(shape)
 
     @staticmethod
     def backward(ctx, dy):
-        xhat, weight, invstd = ctx.saved_tensors
+        xhat, weight, invstd, n = ctx.saved_tensors
         C = xhat.shape[1]
         dims = [d for d in range(xhat.dim()) if d != 1]
         shape = [1, C] + [1] * (xhat.dim() - 2)
@@ -146,7 +199,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
         red[C:] = (dy.double() * xhat.double()).sum(dims)
         d_bias, d_weight = red[:C].to(dy.dtype).clone(), red[C:].to(dy.dtype).clone()   # local: the gradient
         dist.all_reduce(red, op=dist.ReduceOp.SUM)                                       # bucket averages them
-        s1, s2 = (red[:C] / ctx.n).to(dy.dtype), (red[C:] / ctx.n).to(dy.dtype)
+        s1, s2 = (red[:C] / n).to(dy.dtype), (red[C:] / n).to(dy.dtype)
         dx = (weight * invstd).view(shape) * (dy - s1.view(shape) - xhat * s2.view(shape))
         return dx, d_weight, d_bias, None, None, None, None
 

@@ -12,10 +12,13 @@ number of kernels, not the host).  The optimiser has to be capturable (``torch.o
 counters live on the device); the learning rate is a device scalar that ``set_lr`` fills, so the reference's
 per-batch schedule (``Optim.set_lr(epoch + ratio)``, src/pipeline/trainer.py) keeps working under replay.
 
-Multi-rank: the gradient all-reduce sits between backward and clipping (``dist.GradientAllReduce``).  With a
-``reducer`` the step is captured as two graphs -- [zero_grad, forward, backward] and [clip, step] -- and the
-collective runs eagerly between them; a model whose forward itself holds collectives (SyncBatchNorm) cannot be
-captured this way and is refused.
+Multi-rank: the gradient all-reduce sits between backward and clipping (``dist.GradientAllReduce``; every
+``p.grad`` is a view into its flat bucket, so the collective is the only thing added to the step).  On RCCL
+(backend "nccl") collectives are stream-ordered and capturable: the all-reduce -- and the SyncBatchNorm
+collectives of the forward / backward -- are nodes of the SAME graph, one replay per step on every rank.  On a
+backend whose collectives run on the host (gloo: the CPU rehearsals) the step is captured as two graphs --
+[zero_grad, forward, backward] and [clip, step] -- with the collective eager between them; a forward that itself
+holds collectives (SyncBatchNorm) is refused there.
 """
 import torch
 
@@ -57,8 +60,14 @@ class GraphedTrainStep:
                  reducer=None, warmup=3, restore=True):
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a capturable optimiser (graph_step.make_capturable)")
-        if reducer is not None and any(isinstance(m, pdist.SyncBatchNorm1d) for m in model.modules()):
-            raise ValueError("a forward pass with collectives (SyncBatchNorm) cannot be captured; run it eagerly")
+        import torch.distributed as tdist
+        # collectives inside the capture: RCCL only (stream-ordered); host-side backends keep the two-graph form
+        self._fused_collective = (reducer is not None and tdist.is_available() and tdist.is_initialized()
+                                  and tdist.get_backend() == "nccl")
+        if reducer is not None and not self._fused_collective \
+                and any(isinstance(m, pdist.SyncBatchNorm1d) for m in model.modules()):
+            raise ValueError("a forward pass with collectives (SyncBatchNorm) can only be captured on RCCL "
+                             "(backend nccl); run it eagerly")
         self.model, self.optimizer, self.reducer = model, optimizer, reducer
         self.clip = float(grad_norm_clip)
         self.dev = next(model.parameters()).device
@@ -126,6 +135,16 @@ class GraphedTrainStep:
                 self.loss = self._fwd_bwd()
                 self._update()
             self._graphs = [g]
+        elif self._fused_collective:
+            # the collectives are nodes of the graph.  thread_local: the process group's watchdog thread polls
+            # events while this thread captures
+            self.reducer.attach()                      # gradients = views of the bucket BEFORE the capture
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                self.loss = self._fwd_bwd()
+                self.reducer.reduce_()
+                self._update()
+            self._graphs = [g]
         else:
             g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1):
@@ -151,6 +170,9 @@ class GraphedTrainStep:
             self.static[k].copy_(src if torch.is_tensor(src) else torch.as_tensor(src), non_blocking=True)
         if self.reducer is None:
             self._graphs[0].replay()
+        elif self._fused_collective:
+            self._graphs[0].replay()
+            self.reducer._publish_flag()               # the agreed stop flag of this step, read one step later
         else:
             self._graphs[0].replay()
             self.reducer()

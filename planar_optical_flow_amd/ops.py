@@ -170,26 +170,7 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
     if next_batch is not None:
         if B > 65535:
             raise ValueError("chained form needs B <= 65535")
-        nd = next_batch.get("dets")
-        n0, n1 = next_batch.get("odom0"), next_batch.get("odom1")
-        nws = next_batch["workspace"]
-        nxt = _lib.ScanInputs()
-        nxt.want_flow = int("flow" in want)
-        if nxt.want_flow:
-            n0 = _dev(n0, torch.float64, "next odom0")
-            n1 = _dev(n1, torch.float64, "next odom1")
-            nxt.odom0, nxt.odom1, nxt.B = n0.data_ptr(), n1.data_ptr(), n0.shape[0]
-        else:
-            nxt.B = nd.offsets.numel() - 1 if nd is not None else 0
-        if need_det and nd is not None:
-            nxt.det_offsets, nxt.det_rphi, nxt.det_cls = nd.offsets.data_ptr(), nd.rphi.data_ptr(), nd.cls.data_ptr()
-            nxt.D = int(nd.rphi.shape[0])
-        nxt.flow_kind = int(flow_kind)
-        nxt.assoc_radius = (C.c_double * 3)(*assoc_radius)
-        nxt.labels = (C.c_int32 * 3)(*labels)
-        nxt.dyn_radius = (C.c_double * 3)(*dyn_radius)
-        nxt.workspace = nws.data_ptr()
-        nxt.workspace_bytes = nws.numel() * nws.element_size()
+        nxt = _scan_inputs(next_batch, want, flow_kind, assoc_radius, labels, dyn_radius, need_det)
     with torch.cuda.device(dev):
         # grid.y carries the sample index: chunk very large batches
         step = 65535
@@ -213,6 +194,115 @@ def scan_preprocess(scans, tab, odom0=None, odom1=None, dets=None, flow_kind=FLO
                 sl(exc, N), _ptr(workspace), workspace.numel() * workspace.element_size(),
                 C.byref(nxt) if nxt is not None else int(phases), _stream())
     return out
+
+
+_TABF = {}
+
+
+def phi_table_f32(tab):
+    """[N][2] float32 copy of the angle table's (cos, sin) pairs, each rounded once from its float64 entry --
+    exactly what the float32-output preprocess kernel would otherwise convert per point.  Cached per table."""
+    key = (tab.data_ptr(), tab.numel(), tab.device)
+    t = _TABF.get(key)
+    if t is None or t[0]() is not tab:
+        import weakref
+        n = tab.numel() // 3
+        tf = tab[n:].to(torch.float32).contiguous()
+        _TABF[key] = (weakref.ref(tab), tf)
+        return tf
+    return t[1]
+
+
+def _scan_inputs(nb, want, flow_kind, assoc_radius, labels, dyn_radius, need_det):
+    """pof_scan_inputs of one batch whose params are to be evaluated: dict(odom0, odom1, dets, workspace)."""
+    nd = nb.get("dets")
+    n0, n1 = nb.get("odom0"), nb.get("odom1")
+    nws = nb["workspace"]
+    nxt = _lib.ScanInputs()
+    nxt.want_flow = int("flow" in want)
+    if nxt.want_flow:
+        n0 = _dev(n0, torch.float64, "next odom0")
+        n1 = _dev(n1, torch.float64, "next odom1")
+        nxt.odom0, nxt.odom1, nxt.B = n0.data_ptr(), n1.data_ptr(), n0.shape[0]
+    else:
+        nxt.B = nd.offsets.numel() - 1 if nd is not None else 0
+    if need_det and nd is not None:
+        nxt.det_offsets, nxt.det_rphi, nxt.det_cls = nd.offsets.data_ptr(), nd.rphi.data_ptr(), nd.cls.data_ptr()
+        nxt.D = int(nd.rphi.shape[0])
+    nxt.flow_kind = int(flow_kind)
+    nxt.assoc_radius = (C.c_double * 3)(*assoc_radius)
+    nxt.labels = (C.c_int32 * 3)(*labels)
+    nxt.dyn_radius = (C.c_double * 3)(*dyn_radius)
+    nxt.workspace = nws.data_ptr()
+    nxt.workspace_bytes = nws.numel() * nws.element_size()
+    return nxt
+
+
+def scan_preprocess_multi(batches, tab, next_batches=(), flow_kind=FLOW_DISPLACEMENT, canonical=True,
+                          out_dtype=torch.float32, want=("flow",), assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3),
+                          dyn_radius=(2.5, 2.0, 2.0)):
+    """A2-A7 fused for up to 8 batches in ONE launch (pof_scan_preprocess_multi): a loader that runs ahead hands
+    over several ring slots at once.
+
+    batches: list of dict(scans [B,T,N] | [B,N], dets (DetCSR or None), out {name: tensor}, workspace) -- the
+             workspaces must already hold the batches' params (an earlier call's `next_batches`); every name in
+             `want` must be preallocated in `out`.
+    next_batches: list of dict(odom0, odom1, dets, workspace) whose params this launch evaluates on extra
+             workgroups.  `batches` may be empty (params only: priming the ring).
+    """
+    want = set(want)
+    known = {"xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "valid_mask", "exclude_mask"}
+    if not want <= known:
+        raise ValueError("unknown outputs: %s" % sorted(want - known))
+    if len(batches) > _lib.SCAN_MAX_SLOTS or len(next_batches) > _lib.SCAN_MAX_SLOTS:
+        raise ValueError("at most %d batches per launch" % _lib.SCAN_MAX_SLOTS)
+    need_det = bool(want & {"closest", "target_cls", "target_reg", "dyn_mask", "exclude_mask"})
+    tab = _dev(tab, torch.float64, "tab")
+    N = tab.numel() // 3
+    cur = (_lib.ScanBatch * max(len(batches), 1))()
+    keep = []
+    for k, bt in enumerate(batches):
+        scans = _dev(bt["scans"], torch.float32, "scans")
+        if scans.dim() == 3:
+            B, T, n = scans.shape
+            stride, off = T * n, (T - 1) * n
+        elif scans.dim() == 2:
+            B, n = scans.shape
+            stride, off = n, 0
+        else:
+            raise ValueError("scans must be [B,T,N] or [B,N]")
+        if n != N:
+            raise ValueError("angle table is for %d points, scans have %d" % (N, n))
+        dets = bt.get("dets")
+        if need_det and dets is None:
+            raise ValueError("association / dynamic-mask outputs need detections")
+        if dets is not None and dets.offsets.numel() != B + 1:
+            raise ValueError("detection offsets must have B+1 entries")
+        out, ws = bt["out"], bt["workspace"]
+        c = cur[k]
+        c.ranges, c.sample_stride, c.B = scans.data_ptr() + 4 * off, stride, B
+        c.D = int(dets.rphi.shape[0]) if need_det else 0
+        c.det_offsets = dets.offsets.data_ptr() if need_det else None
+        shapes = {"xy": ((B, N, 2), out_dtype), "flow": ((B, N, 2), out_dtype), "closest": ((B, N), torch.int64),
+                  "target_cls": ((B, N), torch.int64), "target_reg": ((B, N, 2), torch.float32),
+                  "dyn_mask": ((B, N), torch.float32), "valid_mask": ((B, N), torch.float32),
+                  "exclude_mask": ((B, N), torch.float32)}
+        for name in known:
+            if name in want:
+                t = _dev(out[name], shapes[name][1], name)
+                if tuple(t.shape) != shapes[name][0]:
+                    raise ValueError("%s has shape %s, expected %s" % (name, tuple(t.shape), shapes[name][0]))
+                setattr(c, name, t.data_ptr())
+        c.workspace, c.workspace_bytes = ws.data_ptr(), ws.numel() * ws.element_size()
+        keep.append((scans, out, ws))
+    nxt = (_lib.ScanInputs * max(len(next_batches), 1))()
+    for k, nb in enumerate(next_batches):
+        nxt[k] = _scan_inputs(nb, want, flow_kind, assoc_radius, labels, dyn_radius, need_det)
+    tabf = phi_table_f32(tab) if out_dtype == torch.float32 else None
+    with torch.cuda.device(tab.device):
+        _lib.call("pof_scan_preprocess_multi", cur, len(batches), nxt, len(next_batches), N, _ptr(tab), _ptr(tabf),
+                  int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
+                  (C.c_double * 3)(*assoc_radius), (C.c_int32 * 3)(*labels), (C.c_double * 3)(*dyn_radius), _stream())
 
 
 def flow_from_xy(xy, odom0, odom1, flow_kind=FLOW_DISPLACEMENT, canonical=False, tab=None):

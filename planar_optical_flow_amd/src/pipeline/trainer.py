@@ -66,8 +66,18 @@ class Trainer:
 
     # ---- training -------------------------------------------------------------------
     def _stop_agreed(self, model):
-        """The local flag, or -- under torch.distributed -- the OR over all ranks (and then set locally too)."""
+        """The local flag, or -- under torch.distributed -- the OR over all ranks (and then set locally too).  With
+        a gradient bucket the flags ride in the step's own all-reduce (its last element): this call reads the answer
+        of the PREVIOUS step (a pinned host word, no blocking copy) and files this rank's request for the next, so
+        every rank leaves the loop at the same step, one step after the first signal."""
         if pdist.is_distributed():
+            self._prepare_distributed(model)
+            if self._reducer is not None:
+                if self._reducer.stop_requested():
+                    self._stop = True
+                    return True
+                self._reducer.set_stop(self._stop)
+                return False
             dev = next(model.parameters()).device
             self._stop = pdist.any_rank(self._stop, dev)
         return self._stop
@@ -105,7 +115,8 @@ class Trainer:
             if self._step != 0:
                 raise RuntimeError("graph_step has to be on from the first step (the optimiser state must be capturable)")
             optim = self._optim.make_capturable()
-            self._graphed = GraphedTrainStep(model, optim, batch, grad_norm_clip=self._grad_norm_clip)
+            self._graphed = GraphedTrainStep(model, optim, batch, grad_norm_clip=self._grad_norm_clip,
+                                             reducer=self._reducer)
             self._graphed_shapes = self._graph_shapes(batch)
         self._optim.set_lr(self._epoch + ratio)
         loss = self._graphed.step(batch).item()
@@ -117,11 +128,14 @@ class Trainer:
     def _train_batch(self, model, batch, ratio):
         self._prepare_distributed(model)
         model.train()
-        if self._graph_step and self._reducer is None and next(model.parameters()).is_cuda \
+        # with a reducer the step is captured only where the collective can be a node of the graph (RCCL)
+        graphable = self._reducer is None or pdist.backend() == "nccl"
+        if self._graph_step and graphable and next(model.parameters()).is_cuda \
                 and (self._graphed is None or self._graph_shapes(batch) == self._graphed_shapes):
             return self._train_batch_graphed(model, batch, ratio)
         # once a step is captured its graph owns the addresses of the gradient buffers: keep them allocated
-        self._optim.zero_grad(set_to_none=self._graphed is None)
+        # (and so does a gradient bucket: the gradients are views into it)
+        self._optim.zero_grad(set_to_none=self._graphed is None and self._reducer is None)
         self._optim.set_lr(self._epoch + ratio)
         loss, tb_dict, _ = model.model_fn(model, batch)
         loss.backward()

@@ -659,6 +659,51 @@ def test_chained_f32_preprocess_b4096_vs_oracle(ops):
         assert max(epe) < 1e-5 and hits > 0, (max(epe), hits)
 
 
+@pytest.mark.parametrize("out_dtype", [torch.float32, torch.float64])
+def test_multi_batch_launch_equals_single_calls(ops, out_dtype):
+    """pof_scan_preprocess_multi: several ring slots (different batch sizes, crowded and empty samples) streamed
+    by ONE launch that also evaluates the params of the next slots == one pof_scan_preprocess call per batch,
+    bit for bit; and against the oracle (association / masks exact) on a few samples."""
+    tab = ops.phi_table()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+    sizes = (513, 64, 1030, 7, 300)
+    slots = []
+    for k, B in enumerate(sizes):
+        sb = synth.make_batch(seed=70 + k, B=B, T=2, max_legs=12 if k == 2 else 6, mixed_classes=(k % 2 == 1))
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        out = {"flow": torch.full((B, 450, 2), 7.0, dtype=out_dtype, device=DEV),
+               "target_cls": torch.full((B, 450), -1, dtype=torch.int64, device=DEV),
+               "target_reg": torch.full((B, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "exclude_mask": torch.full((B, 450), 7.0, dtype=torch.float32, device=DEV)}
+        slots.append({"sb": sb, "scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det,
+                      "workspace": ws, "out": out})
+    ref = [ops.scan_preprocess(s["scans"], tab, s["odom0"], s["odom1"], s["dets"], want=want, out_dtype=out_dtype)
+           for s in slots]
+    # launch 1: params of slots 0..2 only; launch 2: stream 0..2 + params of 3..4; launch 3: stream 3..4
+    ops.scan_preprocess_multi([], tab, next_batches=slots[:3], want=want, out_dtype=out_dtype)
+    ops.scan_preprocess_multi(slots[:3], tab, next_batches=slots[3:], want=want, out_dtype=out_dtype)
+    ops.scan_preprocess_multi(slots[3:], tab, want=want, out_dtype=out_dtype)
+    for k, s in enumerate(slots):
+        for name in want:
+            assert torch.equal(s["out"][name], ref[k][name]), (k, name)
+    phi = R.laser_phi()
+    hits = 0
+    for k in (1, 2):
+        sb, out = slots[k]["sb"], slots[k]["out"]
+        cls, exc = out["target_cls"].cpu().numpy(), out["exclude_mask"].cpu().numpy()
+        for b in range(0, sizes[k], 37):
+            cur = sb.scans[b, -1]
+            xy = np.array(R.polar_to_xy(cur, phi)).T
+            dd = sb.dets[b]
+            c, _ = R.regression_target(cur, phi, dd["wc"], dd["wa"], dd["wp"])
+            assert np.array_equal(cls[b], c), (k, b)
+            m = R.dynamic_mask(xy, dd["wc"], dd["wa"], dd["wp"]) * R.valid_point_mask(cur)
+            assert np.array_equal(exc[b].astype(np.float64), m), (k, b)
+            hits += int((c > 0).sum())
+    assert hits > 0
+
+
 @pytest.mark.parametrize("name", sorted(CUTOUT_CASES))
 def test_cutout_float32_value_path(ops, golden, name):
     """value_mode 1 (approximate-then-verify index, float32 lerp): inds_ct_low identical to the

@@ -173,6 +173,108 @@ def gen_cutout_dense():
     print("cutout_dense.npz:", out.shape, out.dtype)
 
 
+def gen_gradients():
+    """Backward passes of the REFERENCE under torch autograd on the CPU (round 3): upstream gradients are seeded,
+    the fixture holds inputs, upstream gradients and the gradients the reference's own graph produces.
+      A9   Prototype._fusion                 d feat1, d feat2                     prototype.py:118-156
+      A10  _SpatialAttention.forward         d x, d x_template, d emb (both conv outputs), d conv weight / bias /
+                                             BatchNorm affine                     dr_spaam.py:163-217
+      N2   SpatialDROW train-mode step       loss + every parameter's gradient as (sum, abs-sum) and a few whole
+           (model_fn_obj_det)                tensors                              dr_spaam.py:41-121, 220-277
+           Prototype train-mode step         loss (EPE) + gradient summaries      prototype.py:57-109
+    """
+    from src.depracted.model import prototype as proto
+    from src.depracted.model import dr_spaam as spaam
+    from src.utils import eval_utils
+    g = {}
+    # ---- A9
+    torch.manual_seed(141)
+    for tag, shape, kw in (("corr", (2, 256, 57), {}), ("corr_s", (3, 16, 23), {"kernel_size": 3, "max_displacement": 3})):
+        f1 = torch.randn(*shape, requires_grad=True)
+        f2 = torch.randn(*shape, requires_grad=True)
+        out = proto.Prototype._fusion(None, f1, f2, **kw)
+        up = torch.randn_like(out)
+        d1, d2 = torch.autograd.grad(out, [f1, f2], up)
+        g[tag + "_f1"], g[tag + "_f2"], g[tag + "_up"] = f1.detach().numpy(), f2.detach().numpy(), up.numpy()
+        g[tag + "_out"], g[tag + "_d1"], g[tag + "_d2"] = out.detach().numpy(), d1.numpy(), d2.numpy()
+    # ---- A10 (eval-mode BatchNorm in the embedding: the gate's arithmetic without batch coupling)
+    for tag, seed, (B, n_cut, n_ch, n_pts), alpha, w in (("attn", 151, (2, 40, 32, 14), 0.5, 11),
+                                                         ("attn_w7", 152, (1, 19, 8, 5), 0.3, 7)):
+        torch.manual_seed(seed)
+        att = spaam._SpatialAttention(n_pts=n_pts, n_channel=n_ch, alpha=alpha, window_size=w)
+        att.eval()
+        with torch.no_grad():
+            att.conv[1].running_mean.normal_(0, 0.1)
+            att.conv[1].running_var.uniform_(0.5, 1.5)
+        x = torch.randn(B, n_cut, n_ch, n_pts, requires_grad=True)
+        t = torch.randn(B, n_cut, n_ch, n_pts, requires_grad=True)
+        embs = []
+
+        def keep(_m, _i, o):            # the embedding convolution runs twice: x, then the template
+            o.retain_grad()
+            embs.append(o)
+
+        hook = att.conv.register_forward_hook(keep)
+        out, band = att(x, t)
+        hook.remove()
+        up_out, up_band = torch.randn_like(out), torch.randn_like(band)
+        torch.autograd.backward([out, band], [up_out, up_band])
+        for k, v in att.state_dict().items():
+            g[tag + "_sd_" + k.replace(".", "_")] = v.numpy()
+        g[tag + "_x"], g[tag + "_t"] = x.detach().numpy(), t.detach().numpy()
+        g[tag + "_out"], g[tag + "_band"] = out.detach().numpy(), band.detach().numpy()
+        g[tag + "_up_out"], g[tag + "_up_band"] = up_out.numpy(), up_band.numpy()
+        g[tag + "_dx"], g[tag + "_dt"] = x.grad.numpy(), t.grad.numpy()
+        g[tag + "_emb_x"], g[tag + "_emb_t"] = embs[0].detach().numpy(), embs[1].detach().numpy()
+        g[tag + "_demb_x"], g[tag + "_demb_t"] = embs[0].grad.numpy(), embs[1].grad.numpy()
+        for k, p in att.named_parameters():
+            g[tag + "_dp_" + k.replace(".", "_")] = p.grad.numpy()
+    # ---- N2: one SpatialDROW training step (BatchNorm with batch statistics, the reference's own loss adapter)
+    torch.manual_seed(3)
+    mref = spaam.SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True)
+    mref.train()
+    xin = torch.randn(2, 30, 5, 56) * 0.5
+    rs = np.random.default_rng(23)
+    tc = (rs.uniform(size=(2, 30)) < 0.3).astype(np.int64)
+    tr = rs.normal(size=(2, 30, 2)).astype(np.float32)
+    loss, tb, _ = eval_utils.model_fn_obj_det(mref, {"input": xin.numpy(), "target_flow_cls": tc, "target_flow_reg": tr})
+    loss.backward()
+    names = [k for k, _ in mref.named_parameters()]
+    g["sd_x"], g["sd_cls"], g["sd_reg"] = xin.numpy(), tc, tr
+    g["sd_loss"] = np.array([float(loss.detach()), tb["cls_loss"], tb["reg_loss"]])
+    g["sd_names"] = np.array(names)
+    g["sd_gsum"] = np.array([float(p.grad.double().sum()) for _, p in mref.named_parameters()])
+    g["sd_gabs"] = np.array([float(p.grad.double().abs().sum()) for _, p in mref.named_parameters()])
+    whole = ["conv_block_1.0.0.weight", "conv_block_1.0.1.weight", "conv_block_2.2.0.bias", "conv_block_4.1.1.bias",
+             "gate.conv.0.bias", "gate.conv.1.weight", "conv_cls.weight", "conv_reg.weight", "conv_reg.bias"]
+    params = dict(mref.named_parameters())
+    for k in whole:
+        g["sd_grad_" + k.replace(".", "_")] = params[k].grad.numpy()
+    g["sd_grad_conv_block_3_0_0_weight_head"] = params["conv_block_3.0.0.weight"].grad[:8].numpy()
+    g["sd_grad_gate_conv_0_weight_head"] = params["gate.conv.0.weight"].grad[:4].numpy()
+    bufs = dict(mref.named_buffers())
+    g["sd_run_mean_b1"] = bufs["conv_block_1.0.1.running_mean"].numpy()
+    g["sd_run_var_b4"] = bufs["conv_block_4.1.1.running_var"].numpy()
+    # ---- N2: one Prototype training step (EPE loss of prototype.py:27-32)
+    torch.manual_seed(7)
+    pref = proto.Prototype(in_channel=1, max_displacement=5)
+    pref.train()
+    s1, s2 = torch.randn(3, 450, 1), torch.randn(3, 450, 1)
+    tgt = torch.randn(3, 450, 2) * 0.2
+    pred = pref(s1, s2)
+    ploss, _ = proto.flow_loss(pred, tgt)
+    ploss.backward()
+    g["pt_s1"], g["pt_s2"], g["pt_tgt"] = s1.numpy(), s2.numpy(), tgt.numpy()
+    g["pt_pred"], g["pt_loss"] = pred.detach().numpy(), np.array(float(ploss.detach()))
+    g["pt_names"] = np.array([k for k, _ in pref.named_parameters()])
+    g["pt_gsum"] = np.array([float(p.grad.double().sum()) for _, p in pref.named_parameters()])
+    g["pt_gabs"] = np.array([float(p.grad.double().abs().sum()) for _, p in pref.named_parameters()])
+    first = next(iter(pref.named_parameters()))
+    g["pt_grad_first"] = first[1].grad.numpy()
+    g["pt_first_name"] = np.array(first[0])
+    np.savez_compressed(os.path.join(OUT, "gradients.npz"), **g)
+
+
 def main():
     _install_stubs()
     if "--only" in sys.argv:
@@ -690,6 +792,7 @@ def main():
     gen_rotate_iou()
     gen_cutout_dense()
     gen_cutout_indices()
+    gen_gradients()
 
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("wrote", sorted(os.listdir(OUT)), "total bytes", tot)

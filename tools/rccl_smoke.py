@@ -45,5 +45,40 @@ t = torch.ones(4, device="cuda")
 dist.all_reduce(t)
 torch.cuda.synchronize()
 assert t.sum().item() == 4.0
+
+# a whole optimisation step -- SyncBatchNorm collectives, the gradient all-reduce (gradients are views of the flat
+# bucket), Adam -- captured as ONE hipGraph and replayed; against the eager single-process step with stock
+# BatchNorm.  The replayed steps must not synchronise with the host (sync debug mode "error" raises if they do).
+from planar_optical_flow_amd.graph_step import GraphedTrainStep, make_capturable     # noqa: E402
+torch.manual_seed(6)
+gm = get_model(cfg).cuda()
+pd.convert_sync_batchnorm(gm).train()
+torch.manual_seed(6)
+em = get_model(cfg).cuda().train()
+gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, amsgrad=True)
+eopt = torch.optim.Adam(em.parameters(), lr=1e-3, amsgrad=True)
+make_capturable(gopt)
+red2 = pd.GradientAllReduce(gm, always=True)
+gstep = GraphedTrainStep(gm, gopt, {"input": x, "target": y}, reducer=red2)
+assert gstep._fused_collective and len(gstep._graphs) == 1
+assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(red2.params, red2.views))
+worst_loss = 0.0
+for it in range(4):
+    xb = torch.randn(12, 64, 3, device="cuda")
+    yb = torch.randn(12, 3, device="cuda")
+    red2.set_stop(it == 2)
+    torch.cuda.set_sync_debug_mode("error")
+    gl = gstep({"input": xb, "target": yb})
+    torch.cuda.set_sync_debug_mode("default")
+    eopt.zero_grad()
+    el = em.loss_fn(em(xb), yb)
+    el.backward()
+    eopt.step()
+    worst_loss = max(worst_loss, abs(gl.item() - el.item()) / max(abs(el.item()), 1e-6))
+    assert red2.stop_requested() == (it == 2), it       # the flag of THIS step's all-reduce, read after it
+assert worst_loss < 1e-3, worst_loss
+wdiff = max((p - q).abs().max().item() for p, q in zip(gm.parameters(), em.parameters()))
+assert wdiff < 1e-4, wdiff
 dist.destroy_process_group()
-print("RCCL_OK worst relative gradient difference SyncBN vs BatchNorm: %.2e" % worst)
+print("RCCL_OK worst relative gradient difference SyncBN vs BatchNorm: %.2e; captured step with collectives: "
+      "loss diff %.1e, weight diff %.1e, no host sync in the replay" % (worst, worst_loss, wdiff))
