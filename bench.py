@@ -296,7 +296,7 @@ def main():
                 "target_reg": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
                 "exclude_mask": torch.empty((Bm, N), dtype=torch.float32, device=dev),
             }
-            ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, len(rr)), dtype=torch.uint8, device=dev)
+            ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, int(det.rphi.shape[0])), dtype=torch.uint8, device=dev)
             ring.append({"scans": scans, "odom0": o0, "odom1": o1, "dets": det, "out": outs, "workspace": ws})
 
         def trip(n):

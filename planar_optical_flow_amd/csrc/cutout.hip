@@ -22,6 +22,8 @@
 //               outputs, the range rows sit in LDS (loaded into registers at
 //               kernel entry, their latency hidden behind phase A), floor/ratio
 //               use trunc + v_fract (exact in range), np.clip is compare + select.
+#include <cstdlib>
+#include <string>
 #include <type_traits>
 
 #include "pof_common.h"
@@ -473,12 +475,16 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     // Area-sampled windows: output k = float32 mean, in sample order, of the s_area nearest-neighbour samples
     // j = k * s_area ... of the finer grid.  Index of sample j = rint(clip(ia(j))), ia = the rounding sequence
     // of idx with the finer step.  ia is a linear function of j up to ~1e-12 beams, so floor(ia + 0.5) is
-    // tracked in 32.32 fixed point: q(j + 1) = q(j) + dq, two integer adds per sample, the beam is the high
-    // word, four loads in flight.  An output with a sample whose low word comes within 2^-22 beam of a tie
-    // (and every window that leaves the field of view) is summed again with the exact sequence, so the
-    // indices are the reference's in every case.  One output at a time per lane (scalar stores): the sums are
-    // serial anyway, and unrolling them across outputs only costs registers.
-    auto area_group = [&](auto lds_tag, const int p, const int k0) {
+    // tracked in 32.32 fixed point, q(j) = q(0) + j * dq: the beam is the high word.  Truncating dq costs at most
+    // j * 2^-32 < 2^-23 beam over a window (j < P * s_area <= 2^9 * 2^... guarded below), so a sample whose low
+    // word comes within 2^-20 beam of a tie -- and every window that leaves the field of view -- is summed again
+    // with the exact sequence: the indices are the reference's in every case.
+    // Round 3: ONE WAVE PER WINDOW, lane = output k.  Adjacent lanes read beams s_area * c1 ~ s_area apart: an
+    // odd stride over the 64 LDS banks instead of the 8-outputs-per-lane layout's 56-beam stride (8-way
+    // conflicts, 54 % of the LDS-active cycles on the dense shape); the window's parameters are wave-uniform, the
+    // per-output float64 setup (fma, floor, two conversions) becomes one 64-bit multiply-add, and the mean is a
+    // three-instruction correctly rounded division by the launch-constant s_area (tools/divconst32_check.c).
+    auto area_window = [&](auto lds_tag, const int p) {
         auto fetch = [&](int off) -> float { return fetch_from(lds_tag, off); };
         const double a0 = wt.a0[p], step = wt.step[p], step_a = wt.step_a[p];
         const double dd = wt.dd[p];
@@ -489,29 +495,33 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         const double area_c1 = step_a * rdphi;
         const double area_c0 = (a0 - phi0) * rdphi + 0.5;
         // windows that stick out of the field of view, huge N and non-finite windows take the exact loop
-        const bool area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0;
-        const unsigned long long dq = area_fast ? (unsigned long long)(area_c1 * 4294967296.0) : 0ull;
+        const bool area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0 &&
+                               area_c0 >= 0.0 && PA < (1 << 11);
+        unsigned long long q0 = 0, dq = 0;
+        if (area_fast) {
+            const double fl = floor(area_c0);
+            q0 = ((unsigned long long)(unsigned)(int)fl << 32) | (unsigned long long)(unsigned)((area_c0 - fl) * 4294967296.0);
+            dq = (unsigned long long)(area_c1 * 4294967296.0);
+        }
+        const unsigned long long dk = dq * (unsigned long long)s_area;    // per output
+        const float fs = (float)s_area, rs = __fdiv_rn(1.0f, fs);
+        const bool small_div = s_area <= 64;                              // the range divconst32_check.c covers
+        const int lane = threadIdx.x & 63;
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
-            const int o_el = out_off + tt * P + k0;
-#pragma unroll 1
-            for (int u = 0; u < KV; ++u) {
-                const int k = k0 + u;
+            for (int k = lane; k < P; k += 64) {
                 float acc = 0.0f;
                 bool exact = !area_fast;
                 if (area_fast) {
-                    const double x0 = fma((double)(k * s_area), area_c1, area_c0);   // ia(j0) + 0.5 >= 0
-                    const double fl = floor(x0);
-                    unsigned long long q = ((unsigned long long)(unsigned)(int)fl << 32) |
-                                           (unsigned long long)(unsigned)((x0 - fl) * 4294967296.0);
-                    bool near_tie = false;
+                    unsigned long long q = q0 + dk * (unsigned long long)(unsigned)k;
+                    unsigned tie = 0xffffffffu;          // min over the samples of (low word + 2^12) mod 2^32
                     int sdone = 0;
                     for (; sdone + 4 <= s_area; sdone += 4) {
                         const unsigned long long q1 = q + dq, q2 = q1 + dq, q3 = q2 + dq;
                         const float v0 = fetch(roff + (int)(q >> 32)), v1 = fetch(roff + (int)(q1 >> 32));
                         const float v2 = fetch(roff + (int)(q2 >> 32)), v3 = fetch(roff + (int)(q3 >> 32));
-                        near_tie |= ((unsigned)q + 1024u < 2048u) | ((unsigned)q1 + 1024u < 2048u) |
-                                    ((unsigned)q2 + 1024u < 2048u) | ((unsigned)q3 + 1024u < 2048u);
+                        tie = min(min(tie, (unsigned)q + 4096u), min((unsigned)q1 + 4096u, (unsigned)q2 + 4096u));
+                        tie = min(tie, (unsigned)q3 + 4096u);
                         acc = (sdone == 0) ? v0 : acc + v0;
                         acc = acc + v1;
                         acc = acc + v2;
@@ -519,12 +529,12 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
                         q = q3 + dq;
                     }
                     for (; sdone < s_area; ++sdone) {
-                        near_tie |= (unsigned)q + 1024u < 2048u;
+                        tie = min(tie, (unsigned)q + 4096u);
                         const float v = fetch(roff + (int)(q >> 32));
                         acc = (sdone == 0) ? v : acc + v;
                         q += dq;
                     }
-                    exact = near_tie;
+                    exact = tie < 8192u;
                 }
                 if (exact) {
                     for (int s = 0; s < s_area; ++s) {
@@ -536,7 +546,13 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
                         acc = (s == 0) ? v : acc + v;
                     }
                 }
-                const float mean_a = __fdiv_rn(acc, (float)s_area);
+                float mean_a;
+                if (small_div) {        // RN(acc / s_area): q0 = acc * RN(1/s), one exact residual, one correction
+                    const float m0 = acc * rs;
+                    mean_a = fmaf(fmaf(-m0, fs, acc), rs, m0);
+                } else {
+                    mean_a = __fdiv_rn(acc, fs);
+                }
                 float y;
                 if (VMODE == 2) {
                     const float df = (float)dd;
@@ -552,8 +568,9 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
                     const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
                     a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = min(max((int)idx, 0), N - 1);
                 }
-                if (out_tile16) out_tile16[o_el + u] = (_Float16)y;
-                else out_tile[o_el + u] = y;
+                const int o_el = out_off + tt * P + k;
+                if (out_tile16) out_tile16[o_el] = (_Float16)y;
+                else out_tile[o_el] = y;
             }
         }
     };
@@ -578,14 +595,12 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
             if (work) group(std::false_type{}, std::false_type{}, p, k0);
         }
     }
-    // B2: the area-sampled windows, from the list phase A compacted
+    // B2: the area-sampled windows, from the list phase A compacted: one wave per window
     const int n_area = s_area > 0 ? s_acount : 0;
-    for (int g = threadIdx.x; g < n_area * per_win; g += kThreads) {
-        const int q = (P4 > 0) ? g / P4 : g / per_win;
-        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds))
-            area_group(std::true_type{}, wt.alist[q], (g - q * per_win) * KV);
-        else
-            area_group(std::false_type{}, wt.alist[q], (g - q * per_win) * KV);
+    for (int q = threadIdx.x >> 6; q < n_area; q += kWaves) {
+        const int p = __builtin_amdgcn_readfirstlane(wt.alist[q]);
+        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds)) area_window(std::true_type{}, p);
+        else area_window(std::false_type{}, p);
     }
 }
 
@@ -660,7 +675,17 @@ int cutout_launch(const float *scans, int B, int T, int N, const double *tab, in
     a.out = out32; a.out16 = out16; a.s_area = area_mode ? workspace : nullptr; a.dbg_lo = dbg_lo;
     hipStream_t s = pof_stream(stream);
     if (area_mode) {
-        clear_area_kernel<<<(B + 255) / 256, 256, 0, s>>>(workspace, B);
+        // POF_CUTOUT_CLEAR=memset restores round 1's hipMemsetAsync node -- for tools/diag_graph_dump.py only, which
+        // captures and dumps the streaming step in that form WITHOUT replaying it
+        static const bool memset_form = [] {
+            const char *e = std::getenv("POF_CUTOUT_CLEAR");
+            return e && std::string(e) == "memset";
+        }();
+        if (memset_form) {
+            if (hipMemsetAsync(workspace, 0, sizeof(int32_t) * (size_t)B, s) != hipSuccess) return POF_E_LAUNCH;
+        } else {
+            clear_area_kernel<<<(B + 255) / 256, 256, 0, s>>>(workspace, B);
+        }
         POF_CHECK_LAUNCH();
         const int windows = (fixed ? T : 1) * a.Ns;
         int chunks = (windows + kThreads - 1) / kThreads;

@@ -65,8 +65,8 @@ constexpr int kInline = 8;   // detections stored inline in the per-sample recor
 //   flat image    (384 contiguous bytes: what a wave of the flat kernel copies into LDS, 24 lanes x 16 bytes)
 //                 +0    float32 header, 16 floats: [0,7) motion, [7] detection count (int bits), [8,10) class of
 //                       the inline detections (8 x u8), [10,12) "far" flag of the inline detections (8 x u8)
-//                 +64   kInline x float4 {cx, cy, -sd, 0}: the float32 screen (flat_run); unused slots hold the
-//                       null entry {0, 0, +inf, 0}
+//                 +64   kInline x float4 {cx, cy, -sd, sa - sd}: the float32 screen (flat_run); unused slots
+//                       hold the null entry {0, 0, +inf, 0}
 //                 +192  kInline x {cx, cy} float64: centres of the inline detections
 //                 +320  motion[7] + detection count, float64 (float64-output kernels)
 constexpr int kRecImg = 8 + kInline * kDetStride;           // in doubles: byte 448
@@ -83,6 +83,15 @@ constexpr int kRecStride = kRecImg + kImgBytes / 8;         // 104 doubles
 //   kind 0: (sA,cA) = sincos(phi0), (sB,cB) = sincos(phi1)
 //   kind 1: (sA,cA) = sincos(phi0), (sB,cB) = sincos(phi1 - phi0)
 //   kind 2: (sB,cB) = sincos(phi1)
+// A zero the compiler cannot hoist: as a loop-invariant constant vector the zero fields of the records were kept
+// live round the params loop of the flat kernel and spilled (the only scratch use of that kernel).
+__device__ __forceinline__ double opaque_zero()
+{
+    double z;
+    asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+    return z;
+}
+
 __device__ void motion_params(int kind, const double *o0, const double *o1, double sA, double cA,
                               double sB, double cB, double *mot)
 {
@@ -103,18 +112,18 @@ __device__ void motion_params(int kind, const double *o0, const double *o1, doub
         mot[3] = 1.0 - (double)p11;
         mot[4] = fma((double)c0, tx, (double)s0 * ty);
         mot[5] = fma((double)(-s0), tx, (double)c0 * ty);
-        mot[6] = 0.0;
+        mot[6] = opaque_zero();
     } else if (kind == 1) {
         // get_flow_target: float64 throughout
         mot[0] = cB; mot[1] = -sB; mot[2] = sB; mot[3] = cB;
         // trans_world @ rot_0.T
         mot[4] = fma(ty, -sA, tx * cA);
         mot[5] = fma(ty, cA, tx * sA);
-        mot[6] = 0.0;
+        mot[6] = opaque_zero();
     } else if (kind == 2) {
         // get_velocity_from_odometry: float32 R1, cross matrix dphi*[[0,-1],[1,0]]
         const float c1 = (float)cB, s1 = (float)sB;
-        mot[0] = mot[1] = mot[2] = mot[3] = 0.0;
+        mot[0] = mot[1] = mot[2] = mot[3] = opaque_zero();
         mot[4] = fma((double)c1, tx, (double)s1 * ty);
         mot[5] = fma((double)(-s1), tx, (double)c1 * ty);
         mot[6] = o1[2] - o0[2];
@@ -126,7 +135,7 @@ __device__ void motion_params(int kind, const double *o0, const double *o1, doub
         mot[1] = o0[0] / den;   // vx
         mot[2] = o0[1] / den;   // vy
         mot[3] = dt;
-        mot[4] = mot[5] = mot[6] = 0.0;
+        mot[4] = mot[5] = mot[6] = opaque_zero();
     } else {
         // scan-pair alignment (src/utils/dataset.py:76-93): o0 = (dx, dy, dphi), o1[0] = scan_dir
         // (sA,cA) = sincos(dphi), (sB,cB) = sincos(scan_dir); float32 matrices
@@ -134,7 +143,7 @@ __device__ void motion_params(int kind, const double *o0, const double *o1, doub
         mot[0] = (double)c; mot[1] = (double)sn; mot[2] = (double)(-sn); mot[3] = (double)c;
         mot[4] = fma(o0[1], (double)(-sd), o0[0] * (double)cd);
         mot[5] = fma(o0[1], (double)cd, o0[0] * (double)sd);
-        mot[6] = 0.0;
+        mot[6] = opaque_zero();
     }
 }
 
@@ -178,6 +187,84 @@ __device__ __forceinline__ void apply_motion(int kind, double px, double py, dou
 //   ws_det[g] = every detection (CSR order), read only by samples with more
 //               than kInline detections.
 // detection entry = { cx, cy, assoc radius, dyn s-threshold, label, assoc s-threshold }
+// sincos for the params jobs.  The library routine carries the Payne-Hanek reduction for arbitrary magnitudes: 96
+// registers, which the 64-register budget of the flat kernel (8 streaming waves per SIMD) turns into scratch for
+// the whole launch.  Odometry headings and detection bearings are angles of a few radians, so the params jobs use
+// the classic medium-range scheme instead -- Cody-Waite reduction by pi/2 in up to three 33-bit steps (exact
+// products for |n| < 2^20, i.e. |x| < 2^19 * pi/2 ~ 8.2e5 rad) followed by the fdlibm minimax polynomials on
+// [-pi/4, pi/4] with the reduction's tail as correction: below 1 ulp, like the library's.  Beyond that range
+// FALLBACK selects the library routine (the stand-alone params kernel) or NaN (the params blocks inside the flat
+// kernel: documented input domain of the chained / multi entry points).
+__device__ __forceinline__ double poly_sin(double x, double y)
+{
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double z = x * x, v = z * x;
+    const double r = S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)));
+    return x - ((z * (0.5 * y - v * r) - y) - v * S1);
+}
+__device__ __forceinline__ double poly_cos(double x, double y)
+{
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double z = x * x;
+    const double r = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    const double ax = fabs(x);
+    if (ax < 0.3) return 1.0 - (0.5 * z - (z * r - x * y));
+    const double qx = ax > 0.78125 ? 0.28125 : 0.25 * ax;
+    const double hz = 0.5 * z - qx, a = 1.0 - qx;
+    return a - (hz - (z * r - x * y));
+}
+template <bool FALLBACK>
+__device__ __forceinline__ void params_sincos(double x, double *sn, double *cs)
+{
+    const double ax = fabs(x);
+    if (!(ax < 823549.0)) {                 // 2^19 * pi/2 = 823549.66...; NaN and infinities come here too
+        if (FALLBACK) {
+            sincos(x, sn, cs);
+        } else {
+            *sn = *cs = __builtin_nan("");
+        }
+        return;
+    }
+    const double invpio2 = 6.36619772367581382433e-01, p1 = 1.57079632673412561417e+00, p1t = 6.07710050650619224932e-11,
+                 p2 = 6.07710050630396597660e-11, p2t = 2.02226624879595063154e-21, p3 = 2.02226624871116645580e-21,
+                 p3t = 8.47842766036889956997e-32;
+    const double fn = rint(ax * invpio2);
+    double r = ax - fn * p1;                // fn * p1 is exact (20 + 33 bits)
+    double w = fn * p1t;
+    double y0 = r - w;
+    const int ex = (__double2hiint(ax) >> 20) & 0x7ff;
+    if (ex - ((__double2hiint(y0) >> 20) & 0x7ff) > 16) {       // cancellation: the next 33 bits of pi/2
+        double t = r;
+        w = fn * p2;
+        r = t - w;
+        w = fn * p2t - ((t - r) - w);
+        y0 = r - w;
+        if (ex - ((__double2hiint(y0) >> 20) & 0x7ff) > 49) {   // and the next
+            t = r;
+            w = fn * p3;
+            r = t - w;
+            w = fn * p3t - ((t - r) - w);
+            y0 = r - w;
+        }
+    }
+    double y1 = (r - y0) - w;
+    int n = (int)fn;
+    if (x < 0.0) {
+        y0 = -y0;
+        y1 = -y1;
+        n = -n;
+    }
+    const double s = poly_sin(y0, y1), c = poly_cos(y0, y1);
+    switch (n & 3) {
+        case 0: *sn = s; *cs = c; break;
+        case 1: *sn = c; *cs = -s; break;
+        case 2: *sn = -s; *cs = -c; break;
+        default: *sn = -c; *cs = s; break;
+    }
+}
+
 // AP: pointer to the arguments -- a plain pointer to a by-value kernel argument, or a constant-address-space
 // pointer into the kernel-argument segment (slot chosen at run time, scan_flat_kernel)
 template <typename AP>
@@ -195,7 +282,7 @@ __device__ __forceinline__ void det_entry(AP a, int g, double *w)
     w[5] = cl == 0 ? a->sa0 : (cl == 1 ? a->sa1 : a->sa2);   // dist <  assoc radius <=>  s <= w[5]
 }
 
-// float32 screen of the flat kernel (flat_screen).  For a detection j the kernel tracks
+// float32 screen of the flat kernel (flat_run).  For a detection j the kernel tracks
 //   dd_j = fl(ex*ex + fl(ey*ey - sd_j))     ex, ey = float32 point - float32 centre, sd_j rounded to float32
 // and keeps the minimum over the sample's inline detections.  With all coordinates below 100 m and sd <= 400 m^2,
 // |dd_j - (s2_j - sd_j)| <= E(s2_j) = 1e-3 + 1e-4 * s2_j, where s2_j is the float64 squared distance the
@@ -211,74 +298,79 @@ __device__ __forceinline__ bool det_is_far(double cx, double cy, double sd)
     return !(fabs(cx) + fabs(cy) < 100.0) || !(sd <= 400.0);
 }
 
-// number of params jobs of a batch: 2 per sample (the two motion angles) + kInline
-// detection slots per sample
+// number of params jobs of a batch: two per sample
 __host__ __device__ inline int params_job_count(int B, bool have_dets)
 {
-    return 2 * B + (have_dets ? B * kInline : 0);
+    (void)have_dets;
+    return 2 * B;
 }
 
-// job t of the params work: one sincos per lane.  Jobs [0, 2B) = (sample, angle)
-// pairs; then B*kInline detection slots: slot s of a sample evaluates detections
-// s, s+kInline, ... (the first goes into the inline record, and samples with more
-// than kInline detections additionally get all their rows in the CSR table).
-template <typename AP>
+// Params job t: lane `which` = t & 1 of sample t >> 1.  The lane evaluates motion angle `which` (the partner lane
+// t ^ 1 holds the other one; lane 0 combines them) and then the sample's detections which, which + 2, ... -- one
+// sincos per pass of ONE loop -- into the sample's record: the float64 part, the flat image, and for samples with
+// more than kInline detections all rows of the CSR table.
+// Round 3: two lanes per SAMPLE.  Round 2 used one lane per angle and per inline detection slot (10 lanes per
+// sample, one sincos each): five times the wave slots for the same work, held through the same two dependent
+// memory round trips -- with eight batches per launch those blocks took a fifth of the chip's wave slots for the
+// length of their chains (measured: 1.0 us per 4096-scan step).  One loop with one sincos call site and nothing
+// carried round it but indices keeps the job inside the 64 registers of the streaming waves without scratch.
+template <bool FALLBACK, typename AP>
 __device__ __forceinline__ void params_work(AP a, int t)
 {
-    const int nm = 2 * a->B;
-    if (t < nm) {
-        const int b = t >> 1, which = t & 1;
-        const double *o0 = a->odom0 + 3 * b, *o1 = a->odom1 + 3 * b;
-        double s = 0.0, c = 1.0;
-        if (a->flow) {
-            const double ang = motion_angle(a->flow_kind, which, o0, o1);
-            sincos(ang, &s, &c);
+    if (t >= 2 * a->B) return;                 // whole lane pairs: 2 * B is even
+    const int b = t >> 1, which = t & 1;
+    double *rec = a->ws_rec + (long long)b * kRecStride;
+    unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
+    int d0 = 0, cnt = 0;
+    if (a->det_offsets) {
+        d0 = a->det_offsets[b];
+        cnt = a->det_offsets[b + 1] - d0;
+    }
+    // pass 0: the motion angle; pass p >= 1: detection which + 2 (p - 1)
+    const int npass = 1 + (cnt - which + 1) / 2;
+#pragma unroll 1
+    for (int pass = a->flow ? 0 : 1; pass < npass; ++pass) {
+        const int idx = which + 2 * (pass - 1);
+        double ang, dr = 0.0;
+        if (pass == 0) {
+            ang = motion_angle(a->flow_kind, which, a->odom0 + 3 * b, a->odom1 + 3 * b);
+        } else {
+            dr = a->det_rphi[2 * (d0 + idx)];
+            ang = a->det_rphi[2 * (d0 + idx) + 1];
         }
-        // partner lane (t ^ 1) holds the other angle of the same sample
-        const double s_o = __shfl_xor(s, 1, 64), c_o = __shfl_xor(c, 1, 64);
-        if (which == 0) {
-            double *rec = a->ws_rec + (long long)b * kRecStride;
-            unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
-            float *hf = reinterpret_cast<float *>(img);
-            double *m64 = reinterpret_cast<double *>(img + kImgMot);
-            const int cnt = a->det_offsets ? (a->det_offsets[b + 1] - a->det_offsets[b]) : 0;
-            if (a->flow) {
-                motion_params(a->flow_kind, o0, o1, s, c, s_o, c_o, rec);
+        double sn, cs;
+        params_sincos<FALLBACK>(ang, &sn, &cs);
+        if (pass == 0) {
+            // every lane of the wave is here together (pass 0 is each lane's first): the partner's angle
+            const double s_o = __shfl_xor(sn, 1, 64), c_o = __shfl_xor(cs, 1, 64);
+            if (which == 0) {
+                float *hf = reinterpret_cast<float *>(img);
+                double *m64 = reinterpret_cast<double *>(img + kImgMot);
+                motion_params(a->flow_kind, a->odom0 + 3 * b, a->odom1 + 3 * b, sn, cs, s_o, c_o, rec);
 #pragma unroll
                 for (int k = 0; k < 7; ++k) {
                     hf[k] = (float)rec[k];
                     m64[k] = rec[k];
                 }
             }
-            rec[7] = (double)cnt;
-            m64[7] = (double)cnt;
-            reinterpret_cast<int *>(hf)[7] = cnt;
-        }
-    } else if (a->det_offsets && t < nm + a->B * kInline) {
-        const int u = t - nm;
-        const int b = u / kInline, slot = u - b * kInline;
-        const int d0 = a->det_offsets[b], cnt = a->det_offsets[b + 1] - d0;
-        double *rec = a->ws_rec + (long long)b * kRecStride;
-        unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
-        if (slot >= cnt) {
-            // unused inline slot: the null screen entry (never the minimum), class 0, not far
-            reinterpret_cast<float4 *>(img + kImgScreen)[slot] = make_float4(0.0f, 0.0f, INFINITY, 0.0f);
-            img[32 + slot] = 0;
-            img[40 + slot] = 0;
-        }
-        for (int idx = slot; idx < cnt; idx += kInline) {
+        } else {
+            const unsigned cl = a->det_cls[d0 + idx] > 1 ? 2u : (unsigned)a->det_cls[d0 + idx];
             double w[kDetStride];
-            det_entry(a, d0 + idx, w);
+            w[0] = dr * cs;
+            w[1] = dr * sn;
+            w[2] = cl == 0 ? a->ra0 : (cl == 1 ? a->ra1 : a->ra2);
+            w[3] = cl == 0 ? a->sd0 : (cl == 1 ? a->sd1 : a->sd2);   // dist <= dyn radius   <=>  s <= w[3]
+            w[4] = (double)(cl == 0 ? a->lb0 : (cl == 1 ? a->lb1 : a->lb2));
+            w[5] = cl == 0 ? a->sa0 : (cl == 1 ? a->sa1 : a->sa2);   // dist <  assoc radius <=>  s <= w[5]
             if (idx < kInline) {
                 double *r = rec + 8 + idx * kDetStride;
 #pragma unroll
                 for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
                 const bool far = det_is_far(w[0], w[1], w[3]);
                 reinterpret_cast<float4 *>(img + kImgScreen)[idx] =
-                    make_float4((float)w[0], (float)w[1], far ? INFINITY : -(float)w[3], 0.0f);
+                    make_float4((float)w[0], (float)w[1], far ? INFINITY : -(float)w[3], (float)(w[5] - w[3]));
                 reinterpret_cast<double2 *>(img + kImgCtr)[idx] = make_double2(w[0], w[1]);
-                const uint8_t cl = a->det_cls[d0 + idx];
-                img[32 + idx] = cl > 1 ? 2 : cl;
+                img[32 + idx] = (unsigned char)cl;          // byte stores: nothing carried round the loop
                 img[40 + idx] = far ? 1 : 0;
             }
             if (cnt > kInline) {
@@ -288,11 +380,22 @@ __device__ __forceinline__ void params_work(AP a, int t)
             }
         }
     }
+    if (which == 0) {
+        rec[7] = (double)cnt;
+        reinterpret_cast<double *>(img + kImgMot)[7] = (double)cnt;
+        reinterpret_cast<int *>(img)[7] = cnt;
+    }
+    if (!a->det_offsets) return;
+    // unused inline slots: the null screen entry (never the minimum), not far
+    for (int idx = cnt + which; idx < kInline; idx += 2) {
+        reinterpret_cast<float4 *>(img + kImgScreen)[idx] = make_float4(0.0f, 0.0f, INFINITY, 0.0f);
+        img[40 + idx] = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void scan_params_kernel(PreArgs a)
 {
-    params_work(&a, blockIdx.x * blockDim.x + threadIdx.x);
+    params_work<true>(&a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // A value that is the same in every lane, moved to scalar registers.
@@ -676,13 +779,16 @@ struct FlatArgs {
     double ra[3], sd[3], sa[3];
     int lb[3];
     float m_dyn;            // max_c (1e-3 + 1e-4 sd_c), rounded up
-    float thr_assoc;        // max_c (sa_c - sd_c + 1e-3 + 1e-4 sd_c), rounded up
+    float thr_assoc;        // max_c (sa_c - sd_c) + m_assoc, rounded up
+    float m_assoc;          // max_c (1e-3 + 1e-4 max(sd_c, sa_c)) + the rounding of (sa - sd) to float32, rounded up
+    int pad_;
     int wave0[kMaxSlots];   // first wave-chunk of each batch
     FlatBatch b[kMaxSlots];
 };
 
 struct ParamsMulti {
     int nb;
+    int first, total;          // the params blocks are blocks [first, first + total) of the grid
     int blk0[kMaxSlots + 1];   // first params block of each batch (unused slots: the total); blk0[kMaxSlots] = total
     PreArgs p[kMaxSlots];
 };
@@ -926,7 +1032,28 @@ __device__ __forceinline__ void flat_run(const FlatArgs &L, const FlatBatch &bt,
             bool need_dyn = false;
             if (!exk && mind[k] <= -L.m_dyn) dmask[k] = 0.0f;
             else need_dyn = want_dyn && (exk || mind[k] <= L.m_dyn);
-            const bool need_assoc = want_assoc && (exk || mind[k] <= L.thr_assoc);
+            bool need_assoc = want_assoc && (exk || mind[k] <= L.thr_assoc);
+            if (need_assoc && !exk) {
+                // a point near an association disc (a few lanes of most waves): which detection?  The same float32
+                // d_j as above against the detection's own sa_j - sd_j (entry.w): d_j <= w - m surely a candidate,
+                // d_j > w + m surely not.  One sure candidate and nothing in the error band decides the point without
+                // any float64 arithmetic; anything else (overlapping discs, a band) takes the exact loop below.
+                int ncand = 0, jc = 0;
+                bool unsure = false;
+                for (int j = 0; j < n_in; ++j) {
+                    const float4 e = *reinterpret_cast<const float4 *>(ent + 16 * j);
+                    const float exf = pxf[k] - e.x, eyf = pyf[k] - e.y;
+                    const float d = fmaf(exf, exf, fmaf(eyf, eyf, e.z));
+                    if (d <= e.w + L.m_assoc) {
+                        if (d <= e.w - L.m_assoc) { ++ncand; jc = j; }
+                        else unsure = true;
+                    }
+                }
+                if (!unsure && ncand <= 1) {
+                    if (ncand == 1) bidx[k] = jc + 1;
+                    need_assoc = false;
+                }
+            }
             if (need_dyn || need_assoc) {
                 const double pxd = p64x(k), pyd = p64y(k);
                 for (int j = 0; j < n_in; ++j) {
@@ -1021,24 +1148,34 @@ __global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L,
     constexpr int WAVES = THREADS / 64;
     __shared__ __align__(16) unsigned char smem[WAVES][kWaveLds];
     kernarg_ptr ka = (kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-    if ((int)blockIdx.x >= L.main_blocks) {
-        // params blocks: a block belongs to ONE batch (uniform slot index -> scalar loads of its arguments)
-        const int blk = (int)blockIdx.x - L.main_blocks;
-        int k = 0;
+    // Role of this block.  The params blocks (P.total of them) sit at block indices [P.first, P.first + P.total):
+    // behind the streaming blocks they would form the launch's tail (their chains -- offsets -> detection ->
+    // sincos -> stores -- are two dependent memory round trips long), in front of them they would hold the slots the
+    // first streaming waves need; in the middle their latency hides under the streaming waves around them.
+    int sblock = (int)blockIdx.x;
+    if (sblock >= P.first) {
+        if (sblock < P.first + P.total) {
+#ifndef POF_FLAT_NO_PARAMS
+            // a params block belongs to ONE batch (uniform slot index -> scalar loads of its arguments)
+            const int blk = sblock - P.first;
+            int k = 0;
 #pragma unroll
-        for (int i = 1; i < kMaxSlots; ++i) k += (blk >= P.blk0[i]) ? 1 : 0;
-        k = __builtin_amdgcn_readfirstlane(k);
-        int b0 = P.blk0[0];
+            for (int i = 1; i < kMaxSlots; ++i) k += (blk >= P.blk0[i]) ? 1 : 0;
+            k = __builtin_amdgcn_readfirstlane(k);
+            int b0 = P.blk0[0];
 #pragma unroll
-        for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
-        const auto *pa = reinterpret_cast<const __attribute__((address_space(4))) PreArgs *>(
-            ka + kFlatArgsKernargBytes + offsetof(ParamsMulti, p) + (size_t)k * sizeof(PreArgs));
-        params_work(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
-        return;
+            for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
+            const auto *pa = reinterpret_cast<const __attribute__((address_space(4))) PreArgs *>(
+                ka + kFlatArgsKernargBytes + offsetof(ParamsMulti, p) + (size_t)k * sizeof(PreArgs));
+            params_work<false>(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
+#endif
+            return;
+        }
+        sblock -= P.total;
     }
     const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int lane = (int)threadIdx.x & 63;
-    const int w = (int)blockIdx.x * WAVES + wv;
+    const int w = sblock * WAVES + wv;
     if (w >= L.total_waves) return;
     // batch of this wave-chunk: wave0[i] of the unused slots is INT_MAX
     int k = 0;
@@ -1146,7 +1283,7 @@ __global__ __launch_bounds__(kThreads, 8) void scan_preprocess_chain_kernel(PreA
     // params rows LAST: measured 20.2 us per step against 22.7 us with the params rows first
     // (dispatched first, their long sincos chains hold CU slots the streaming rows need)
     if ((int)blockIdx.y >= main_rows) {
-        if (blockIdx.x == 0) params_work(&nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
+        if (blockIdx.x == 0) params_work<false>(&nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
         return;
     }
     scan_main<OutT, PTS, SPB>(a, blockIdx.y);
@@ -1295,24 +1432,29 @@ float f32_round_up(double v)
     return f;
 }
 
-// tuning knobs of the flat kernel (threads per workgroup, 128-point runs per wave), POF_FLAT_TUNE="threads,cpw"
-void flat_tuning(int *threads, int *cpw)
+// tuning knobs of the flat kernel, POF_FLAT_TUNE="threads,cpw[,ppos]": threads per workgroup, 128-point runs per
+// wave, position of the params blocks in the grid in percent of the streaming blocks (0 first ... 100 last)
+void flat_tuning(int *threads, int *cpw, int *ppos)
 {
-    static int t = 0, c = 0;
+    static int t = 0, c = 0, pp = 0;
     if (t == 0) {
-        int tt = 128, cc = 1;
+        int tt = 128, cc = 1, qq = 50;
         if (const char *e = std::getenv("POF_FLAT_TUNE")) {
-            int a = 0, b = 0;
-            if (std::sscanf(e, "%d,%d", &a, &b) == 2 && (a == 64 || a == 128 || a == 256) && (b == 1 || b == 2)) {
+            int a = 0, b = 0, q = 50;
+            const int n = std::sscanf(e, "%d,%d,%d", &a, &b, &q);
+            if (n >= 2 && (a == 64 || a == 128 || a == 256) && (b == 1 || b == 2)) {
                 tt = a;
                 cc = b;
+                if (n == 3 && q >= 0 && q <= 100) qq = q;
             }
         }
         c = cc;
+        pp = qq;
         t = tt;
     }
     *threads = t;
     *cpw = c;
+    *ppos = pp;
 }
 
 struct FlatCommon {
@@ -1384,8 +1526,8 @@ int bind_next(const pof_scan_inputs *next, PreArgs &nx, int *jobs)
 int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_scan_inputs *const *next, int n_next,
                 hipStream_t s)
 {
-    int threads, cpw;
-    flat_tuning(&threads, &cpw);
+    int threads, cpw, ppos;
+    flat_tuning(&threads, &cpw, &ppos);
     if (!flat_shape_ok(c.N, cpw)) cpw = 1;
     FlatArgs L = {};
     L.tab = c.tab; L.tabf = c.tabf; L.N = c.N; L.halfN = c.N / 2;
@@ -1401,14 +1543,16 @@ int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_
     L.sd[0] = cc.sd0; L.sd[1] = cc.sd1; L.sd[2] = cc.sd2;
     L.sa[0] = cc.sa0; L.sa[1] = cc.sa1; L.sa[2] = cc.sa2;
     L.lb[0] = cc.lb0; L.lb[1] = cc.lb1; L.lb[2] = cc.lb2;
-    double md = 0.0, ta = -HUGE_VAL;
+    double md = 0.0, ma = 0.0, gap = -HUGE_VAL, span = 0.0;
     for (int k = 0; k < 3; ++k) {
-        const double m = 1e-3 + 1e-4 * std::fmax(L.sd[k], 0.0);
-        md = std::fmax(md, m);
-        ta = std::fmax(ta, L.sa[k] - L.sd[k] + m);
+        md = std::fmax(md, 1e-3 + 1e-4 * std::fmax(L.sd[k], 0.0));
+        ma = std::fmax(ma, 1e-3 + 1e-4 * std::fmax(std::fmax(L.sd[k], L.sa[k]), 0.0));
+        gap = std::fmax(gap, L.sa[k] - L.sd[k]);
+        span = std::fmax(span, std::fabs(L.sa[k] - L.sd[k]));
     }
     L.m_dyn = f32_round_up(md * (1.0 + 1e-6));
-    L.thr_assoc = f32_round_up(ta + 1e-6 * std::fabs(ta));
+    L.m_assoc = f32_round_up(ma * 1.001 + 2.4e-7 * span);
+    L.thr_assoc = f32_round_up(gap + (double)L.m_assoc + 1e-6 * std::fabs(gap));
     long long waves = 0;
     const long long pairs_per_wave = 64LL * cpw;
     for (int i = 0; i < n_cur; ++i) {
@@ -1438,6 +1582,8 @@ int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_
         ++P.nb;
     }
     for (int i = P.nb; i <= kMaxSlots; ++i) P.blk0[i] = extra;
+    P.total = extra;
+    P.first = (int)((long long)L.main_blocks * ppos / 100);
     if (L.main_blocks + extra == 0) return POF_OK;
     dim3 grid((unsigned)(L.main_blocks + extra));
     const bool headline = (L.flags == (unsigned)kCfgHeadline);

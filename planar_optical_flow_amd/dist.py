@@ -173,7 +173,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
         stat = torch.empty(2 * C + 1, dtype=torch.float64, device=x.device)
         stat[:C] = xd.sum(dims)
         stat[C:2 * C] = (xd * xd).sum(dims)
-        stat[2 * C] = x.numel() // C
+        stat[2 * C:].fill_(float(x.numel() // C))      # a fill kernel: no host-to-device copy (capturable)
         dist.all_reduce(stat, op=dist.ReduceOp.SUM)
         n = stat[2 * C]
         mean = stat[:C] / n

@@ -377,10 +377,13 @@ def canonical_to_det(ranges, tab, dx, dy):
 
 def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, window_depth=1.0,
            num_cutout_pts=48, padding_val=29.99, area_mode=False, out=None, return_debug=False,
-           exact_values=True, out_dtype=torch.float32):
+           exact_values=True, out_dtype=torch.float32, workspace=None):
     """A8 for a batch: scans [B,T,N] float32 -> [B, ceil(N/stride), T, P] float32.
     exact_values=False selects the float32 value path (exact indices, values within 1e-5);
-    out_dtype=torch.float16 stores the result as float16 (BASELINE config 5)."""
+    out_dtype=torch.float16 stores the result as float16 (BASELINE config 5).
+    workspace: optional caller-owned int32 tensor of >= min(B, 65535) elements (the per-sample area maxima); a
+    caller that captures this call in a hipGraph passes one it allocated BEFORE the capture, so that the graph
+    holds no allocation of its own for it (streaming.StreamingDetector)."""
     if out_dtype not in (torch.float32, torch.float16):
         raise TypeError("out_dtype must be float32 or float16")
     scans = _dev(scans, torch.float32, "scans")
@@ -404,7 +407,12 @@ def cutout(scans, tab, stride=1, centered=True, fixed=False, window_width=1.66, 
         step = 65535
         for s in range(0, B, step):
             n = min(step, B - s)
-            ws = torch.empty(max(n, 1), dtype=torch.int32, device=scans.device)
+            if workspace is not None:
+                ws = _dev(workspace, torch.int32, "workspace")
+                if ws.numel() < n:
+                    raise ValueError("workspace must hold at least %d int32 elements" % n)
+            else:
+                ws = torch.empty(max(n, 1), dtype=torch.int32, device=scans.device)
             _lib.call(entry, _ptr(scans[s:s + n]), n, T, N, _ptr(tab), int(stride), int(bool(centered)),
                       int(bool(fixed)), float(window_width), float(window_depth), P, float(padding_val),
                       int(bool(area_mode)), 0 if exact_values else 1, _ptr(out[s:s + n]), _ptr(ws),

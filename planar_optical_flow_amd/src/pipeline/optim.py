@@ -20,7 +20,13 @@ class Optim:
 
     def __init__(self, model, cfg):
         self._schedule = dict(cfg["scheduler_kwargs"])
-        self._optim = torch.optim.Adam(model.parameters(), amsgrad=True)
+        params = list(model.parameters())
+        # on the device: the fused multi-tensor Adam -- ONE launch for all 72 parameter tensors of the box head
+        # instead of ~220 element-wise launches per step (round 2's profile: 16 016 DivFunctor launches in 73 steps);
+        # same update rule (amsgrad), capturable in a hipGraph
+        fused = len(params) > 0 and all(p.is_cuda and p.is_floating_point() for p in params)
+        self._optim = torch.optim.Adam(params, amsgrad=True, fused=True) if fused \
+            else torch.optim.Adam(params, amsgrad=True)
 
     def __getattr__(self, name):
         if name in Optim._FORWARDED:

@@ -47,6 +47,9 @@ class StreamingDetector:
         self.tab = ops.phi_table(num_pts=self.N, device=dev) if angle_inc is None \
             else ops.phi_table(angle_inc, self.N, device=dev)
         self._scan = torch.zeros((self.B, 1, self.N), dtype=torch.float32, device=dev)
+        # the cutout's per-sample workspace is the detector's, allocated before any capture: the captured step
+        # then holds no allocation that is made and dropped inside the capture
+        self._cut_ws = torch.zeros(max(self.B, 1), dtype=torch.int32, device=dev)
         self._use_graph = bool(graph)
         self._nms = None if nms_min_dist is None else float(nms_min_dist)
         self._dets = None
@@ -71,7 +74,7 @@ class StreamingDetector:
 
     # one step on the static buffers; `first` = no template yet
     def _step(self, first):
-        x = ops.cutout(self._scan, self.tab, **self.kw)
+        x = ops.cutout(self._scan, self.tab, workspace=self._cut_ws, **self.kw)
         with torch.no_grad():
             cls, reg, tmpl, fused = self.model(x, testing=True, fea_template=None if first else self.template)
             if self._nms is not None:

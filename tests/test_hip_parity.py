@@ -704,6 +704,42 @@ def test_multi_batch_launch_equals_single_calls(ops, out_dtype):
     assert hits > 0
 
 
+def test_params_sincos_domain(ops):
+    """The params jobs evaluate sincos with a medium-range reduction (|angle| < 2^19 pi/2 ~ 8.2e5 rad).  Inside the
+    range: headings of hundreds of radians and bearings anywhere in the field of view agree with the oracle
+    (float64 flow <= 1e-12 m, association exact).  Beyond it the stand-alone params launch (pof_scan_preprocess)
+    falls back to the library routine and stays exact; the chained / multi forms return NaN for that sample only."""
+    tab = ops.phi_table()
+    sb = synth.make_batch(seed=91, B=64, T=2)
+    rs = np.random.default_rng(5)
+    sb.odom0[:, 2] = rs.uniform(-800.0, 800.0, 64)
+    sb.odom1[:, 2] = sb.odom0[:, 2] + rs.uniform(-0.03, 0.03, 64)
+    sb.odom0[7, 2], sb.odom1[7, 2] = 1.0e6, 1.0e6 + 0.01          # outside the medium range
+    det = csr(ops, sb)
+    want = ("flow", "target_cls")
+    out = ops.scan_preprocess(T(sb.scans), tab, T(sb.odom0), T(sb.odom1), det, want=want, out_dtype=torch.float64)
+    phi = R.laser_phi()
+    flow, cls = out["flow"].cpu().numpy(), out["target_cls"].cpu().numpy()
+    for b in range(64):
+        cur = sb.scans[b, -1]
+        xy = np.array(R.polar_to_xy(cur, phi)).T
+        ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
+        np.testing.assert_allclose(flow[b], ref, rtol=0, atol=1e-12)
+        dd = sb.dets[b]
+        c, _ = R.regression_target(cur, phi, dd["wc"], dd["wa"], dd["wp"])
+        assert np.array_equal(cls[b], c), b
+    ws = torch.empty(ops.scan_preprocess_workspace_bytes(64, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+    o2 = {"flow": torch.zeros((64, 450, 2), dtype=torch.float64, device=DEV),
+          "target_cls": torch.zeros((64, 450), dtype=torch.int64, device=DEV)}
+    slot = {"scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det, "workspace": ws, "out": o2}
+    ops.scan_preprocess_multi([], tab, next_batches=[slot], want=want, out_dtype=torch.float64)
+    ops.scan_preprocess_multi([slot], tab, want=want, out_dtype=torch.float64)
+    f2 = o2["flow"].cpu().numpy()
+    assert np.isnan(f2[7]).all()
+    keep = np.arange(64) != 7
+    assert np.array_equal(f2[keep], flow[keep]) and torch.equal(o2["target_cls"], out["target_cls"])
+
+
 @pytest.mark.parametrize("name", sorted(CUTOUT_CASES))
 def test_cutout_float32_value_path(ops, golden, name):
     """value_mode 1 (approximate-then-verify index, float32 lerp): inds_ct_low identical to the

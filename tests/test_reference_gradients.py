@@ -107,12 +107,16 @@ def test_spatial_drow_training_step_equals_reference(golden):
     names = [k for k, _ in m.named_parameters()]
     assert names == list(g["sd_names"])
     params = dict(m.named_parameters())
-    # every parameter: signed sum and absolute sum of its gradient (bar relative to the absolute sum)
+    # every parameter: signed sum and absolute sum of its gradient.  Bar: 2e-3 of the gradient's own absolute sum
+    # plus 1e-6 of the largest one -- a convolution bias in front of a BatchNorm has a mathematically zero
+    # gradient, what either side holds there is round-off (2e-5 in the reference, 4e-6 here)
+    top = float(g["sd_gabs"].max())
     for i, k in enumerate(names):
         gr = params[k].grad.double()
         ab = float(g["sd_gabs"][i])
-        assert abs(float(gr.abs().sum()) - ab) <= 2e-3 * ab + 1e-7, (k, float(gr.abs().sum()), ab)
-        assert abs(float(gr.sum()) - float(g["sd_gsum"][i])) <= 2e-3 * ab + 1e-7, (k, float(gr.sum()), g["sd_gsum"][i])
+        tol = 2e-3 * ab + 1e-6 * top
+        assert abs(float(gr.abs().sum()) - ab) <= tol, (k, float(gr.abs().sum()), ab)
+        assert abs(float(gr.sum()) - float(g["sd_gsum"][i])) <= tol, (k, float(gr.sum()), g["sd_gsum"][i])
     # whole tensors
     for key in g.files:
         if not key.startswith("sd_grad_"):
@@ -124,7 +128,9 @@ def test_spatial_drow_training_step_equals_reference(golden):
         assert len(match) == 1, name
         gr = params[match[0]].grad
         want = g[key]
-        close(gr[:want.shape[0]] if head else gr, want, 1e-3, "d " + match[0])
+        got = (gr[:want.shape[0]] if head else gr).detach().cpu().numpy()
+        err = float(np.abs(got.astype(np.float64) - want).max())
+        assert err <= 1e-3 * float(np.abs(want).max()) + 1e-8 * top, (match[0], err, float(np.abs(want).max()))
     bufs = dict(m.named_buffers())
     close(bufs["conv_block_1.0.1.running_mean"], g["sd_run_mean_b1"], 1e-4, "running mean")
     close(bufs["conv_block_4.1.1.running_var"], g["sd_run_var_b4"], 1e-4, "running var")
