@@ -75,6 +75,8 @@ def parse():
                          "and evaluates the params of the next `slots`)")
     ap.add_argument("--dets-per-sample", type=int, default=-1,
                     help="ablation: exactly this many detections per sample instead of the synthetic 0..6 legs")
+    ap.add_argument("--no-single", action="store_true",
+                    help="skip the one-batch-per-launch and float64 legs (PMC passes: one launch shape per kernel name)")
     ap.add_argument("--no-params", action="store_true",
                     help="ablation: the timed launches do not evaluate the next slots' params (they are constant)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -377,12 +379,14 @@ def main():
 
     weak = measure(sb, a.slots)
     # the same steps one batch per launch (the per-kernel duration rocprofv3 reports for THAT form is one step)
-    single = measure(sb, 1) if a.slots > 1 else None
+    single = measure(sb, 1) if (a.slots > 1 and not a.no_single) else None
     # the float64-output instantiation (the reference's float64 operation order for the flow: utils.py:47-48,
     # 639-662), same region shape
-    f64 = measure(sb, a.slots, torch.float64)
-    f64_out = f64["ring"][0]["out"]["flow"][:64].cpu().numpy()
-    f64 = {k: v for k, v in f64.items() if k != "ring"}
+    f64 = f64_out = None
+    if not a.no_single:
+        f64 = measure(sb, a.slots, torch.float64)
+        f64_out = f64["ring"][0]["out"]["flow"][:64].cpu().numpy()
+        f64 = {k: v for k, v in f64.items() if k != "ring"}
     torch.cuda.empty_cache()
     dt = float(np.median(weak["wall_s"]))
     dev_ms = float(np.median(weak["dev_ms"]))
@@ -415,7 +419,8 @@ def main():
         xy = np.array(R.polar_to_xy(cur, phi)).T
         ref = R.flow_to_canonical(R.displacement_from_odometry(xy, sb.odom0[b], sb.odom1[b]), phi)
         epe += float(np.linalg.norm(flow[b] - ref, axis=-1).mean()) / 64
-        epe64 += float(np.linalg.norm(f64_out[b] - ref, axis=-1).mean()) / 64
+        if f64_out is not None:
+            epe64 += float(np.linalg.norm(f64_out[b] - ref, axis=-1).mean()) / 64
 
     # the training rows run on all ranks (they hold collectives).  They are extras: an error in one of them (the
     # same on every rank) is reported in its place instead of costing the line its headline measurement
@@ -486,27 +491,32 @@ def main():
                          "traffic_source": traffic_src,
                          "clock": "wall (the interval of ms_per_step)",
                          "bytes_per_step": bytes_per_scan * B,
-                         "bytes_per_launch": bytes_per_scan * B * S, "launch_ms": ms_step * S,
-                         "steps_per_launch": S,
+                         # K steps are ceil(K / S) launches (the last one may stream fewer slots): per-launch
+                         # figures are averages over those launches
+                         "bytes_per_launch": bytes_per_scan * B * a.steps / weak["launches"],
+                         "launch_ms": ms_step * a.steps / weak["launches"],
+                         "launches": weak["launches"], "steps_per_launch": S,
                          "events": {"ms_per_step": ev_step, "achieved": bytes_per_scan * B / (ev_step * 1e-3) / 1e9,
                                     "frac": bytes_per_scan * B / (ev_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                     "ms_per_step_min": min(weak["dev_ms"]) / a.steps,
                                     "ms_per_step_max": max(weak["dev_ms"]) / a.steps,
                                     "note": "HIP events on the launch stream around the same K-step region"},
-                         "note": "one kernel launch covers %d steps (ring slots): a per-kernel duration as rocprofv3 "
-                                 "lists it is launch_ms = %d x ms_per_step; `traffic` is per launch as well" % (S, S)},
+                         "note": "one kernel launch covers up to %d steps (ring slots): a per-kernel duration as "
+                                 "rocprofv3 lists it is launch_ms = ms_per_step x steps / launches (%d x ms_per_step for "
+                                 "full launches); `traffic` is per full launch" % (S, S)},
         }
-        f_dt = float(np.median(f64["wall_s"]))
-        f_ms = f_dt / a.steps * 1e3
-        f_ach = bytes_per_scan_f64 * B / (f_ms * 1e-3) / 1e9
-        result["value_f64"] = world * B * a.steps / f_dt
-        result["roofline_f64"] = {"bound": "hbm", "kernel": "scan_flat_kernel<double, headline cfg>",
-                                  "dtype": "f64 flow arithmetic in the reference's operation order, float64 flow output",
-                                  "ms_per_step": f_ms, "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": f_ach / HBM_PEAK_GBS, "bytes_per_step": bytes_per_scan_f64 * B,
-                                  "steps_per_launch": f64["slots"], "clock": "wall",
-                                  "events_ms_per_step": float(np.median(f64["dev_ms"])) / a.steps,
-                                  "epe_vs_oracle_m": epe64, "traffic": None}
+        if f64 is not None:
+            f_dt = float(np.median(f64["wall_s"]))
+            f_ms = f_dt / a.steps * 1e3
+            f_ach = bytes_per_scan_f64 * B / (f_ms * 1e-3) / 1e9
+            result["value_f64"] = world * B * a.steps / f_dt
+            result["roofline_f64"] = {"bound": "hbm", "kernel": "scan_flat_kernel<double, headline cfg>",
+                                      "dtype": "f64 flow arithmetic in the reference's operation order, float64 flow output",
+                                      "ms_per_step": f_ms, "achieved": f_ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": f_ach / HBM_PEAK_GBS, "bytes_per_step": bytes_per_scan_f64 * B,
+                                      "steps_per_launch": f64["slots"], "clock": "wall",
+                                      "events_ms_per_step": float(np.median(f64["dev_ms"])) / a.steps,
+                                      "epe_vs_oracle_m": epe64, "traffic": None}
         if single is not None:
             s_dev = float(np.median(single["dev_ms"])) / a.steps
             s_wall = float(np.median(single["wall_s"]))

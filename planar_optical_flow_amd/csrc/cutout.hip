@@ -476,17 +476,19 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     // j = k * s_area ... of the finer grid.  Index of sample j = rint(clip(ia(j))), ia = the rounding sequence
     // of idx with the finer step.  ia is a linear function of j up to ~1e-12 beams, so floor(ia + 0.5) is
     // tracked in 32.32 fixed point, q(j) = q(0) + j * dq: the beam is the high word.  Truncating dq costs at most
-    // j * 2^-32 < 2^-23 beam over a window (j < P * s_area <= 2^9 * 2^... guarded below), so a sample whose low
-    // word comes within 2^-20 beam of a tie -- and every window that leaves the field of view -- is summed again
-    // with the exact sequence: the indices are the reference's in every case.
-    // Round 3: ONE WAVE PER WINDOW, lane = output k.  Adjacent lanes read beams s_area * c1 ~ s_area apart: an
-    // odd stride over the 64 LDS banks instead of the 8-outputs-per-lane layout's 56-beam stride (8-way
-    // conflicts, 54 % of the LDS-active cycles on the dense shape); the window's parameters are wave-uniform, the
-    // per-output float64 setup (fma, floor, two conversions) becomes one 64-bit multiply-add, and the mean is a
-    // three-instruction correctly rounded division by the launch-constant s_area (tools/divconst32_check.c).
-    auto area_window = [&](auto lds_tag, const int p) {
+    // j * 2^-32 < 2^-21 beam over a window (P * s_area < 2^11, guarded below), so an output with a sample whose
+    // low word comes within 2^-20 beam of a tie -- and every window that leaves the field of view -- is summed
+    // again with the exact sequence: the indices are the reference's in every case.
+    // Round 3: one call = `k_count` consecutive outputs of ONE window from k_begin on.  The window's parameters
+    // are read once per call, the per-output float64 setup (fma, floor, two conversions) is one 64-bit add, the
+    // mean is a three-instruction correctly rounded division by the launch-constant s_area
+    // (tools/divconst32_check.c), and the outputs leave as 16-byte stores (round 2 stored every output on its
+    // own: one line transaction per output, 0.26 ms of memory-pipe time on the dense shape).
+    const float area_fs = (float)max(s_area, 1), area_rs = __fdiv_rn(1.0f, area_fs);
+    const bool area_small_div = s_area <= 64;                   // the range divconst32_check.c covers
+    auto area_outputs = [&](auto lds_tag, const int p, const int k_begin, const int k_count) {
         auto fetch = [&](int off) -> float { return fetch_from(lds_tag, off); };
-        const double a0 = wt.a0[p], step = wt.step[p], step_a = wt.step_a[p];
+        const double a0 = wt.a0[p], step_a = wt.step_a[p];
         const double dd = wt.dd[p];
         const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
@@ -497,80 +499,98 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         // windows that stick out of the field of view, huge N and non-finite windows take the exact loop
         const bool area_fast = (kr == ((P - 1) << 16)) && N < (1 << 30) && area_c1 >= 0.0 && area_c1 < 1024.0 &&
                                area_c0 >= 0.0 && PA < (1 << 11);
-        unsigned long long q0 = 0, dq = 0;
+        unsigned long long dq = 0, dk = 0, qk0 = 0;
         if (area_fast) {
             const double fl = floor(area_c0);
-            q0 = ((unsigned long long)(unsigned)(int)fl << 32) | (unsigned long long)(unsigned)((area_c0 - fl) * 4294967296.0);
+            const unsigned long long q0 =
+                ((unsigned long long)(unsigned)(int)fl << 32) | (unsigned long long)(unsigned)((area_c0 - fl) * 4294967296.0);
             dq = (unsigned long long)(area_c1 * 4294967296.0);
+            dk = dq * (unsigned long long)s_area;                // per output
+            qk0 = q0 + dk * (unsigned long long)(unsigned)k_begin;
         }
-        const unsigned long long dk = dq * (unsigned long long)s_area;    // per output
-        const float fs = (float)s_area, rs = __fdiv_rn(1.0f, fs);
-        const bool small_div = s_area <= 64;                              // the range divconst32_check.c covers
-        const int lane = threadIdx.x & 63;
+        constexpr int VS = (P4 >= 0) ? 4 : 1;                    // outputs per store
         for (int tt = 0; tt < tcount; ++tt) {
             const int roff = (row_off + tt) * rstride + rbase;
-            for (int k = lane; k < P; k += 64) {
-                float acc = 0.0f;
-                bool exact = !area_fast;
-                if (area_fast) {
-                    unsigned long long q = q0 + dk * (unsigned long long)(unsigned)k;
-                    unsigned tie = 0xffffffffu;          // min over the samples of (low word + 2^12) mod 2^32
-                    int sdone = 0;
-                    for (; sdone + 4 <= s_area; sdone += 4) {
-                        const unsigned long long q1 = q + dq, q2 = q1 + dq, q3 = q2 + dq;
-                        const float v0 = fetch(roff + (int)(q >> 32)), v1 = fetch(roff + (int)(q1 >> 32));
-                        const float v2 = fetch(roff + (int)(q2 >> 32)), v3 = fetch(roff + (int)(q3 >> 32));
-                        tie = min(min(tie, (unsigned)q + 4096u), min((unsigned)q1 + 4096u, (unsigned)q2 + 4096u));
-                        tie = min(tie, (unsigned)q3 + 4096u);
-                        acc = (sdone == 0) ? v0 : acc + v0;
-                        acc = acc + v1;
-                        acc = acc + v2;
-                        acc = acc + v3;
-                        q = q3 + dq;
+            unsigned long long qk = qk0;
+            for (int kb = k_begin; kb < k_begin + k_count; kb += VS) {
+                float yv[VS];
+#pragma unroll
+                for (int u = 0; u < VS; ++u) {
+                    const int k = kb + u;
+                    float acc = 0.0f;
+                    bool exact = !area_fast;
+                    if (area_fast) {
+                        unsigned long long q = qk;
+                        unsigned tie = 0xffffffffu;      // min over the samples of (low word + 2^12) mod 2^32
+                        int sdone = 0;
+                        for (; sdone + 4 <= s_area; sdone += 4) {
+                            const unsigned long long q1 = q + dq, q2 = q1 + dq, q3 = q2 + dq;
+                            const float v0 = fetch(roff + (int)(q >> 32)), v1 = fetch(roff + (int)(q1 >> 32));
+                            const float v2 = fetch(roff + (int)(q2 >> 32)), v3 = fetch(roff + (int)(q3 >> 32));
+                            tie = min(min(tie, (unsigned)q + 4096u), min((unsigned)q1 + 4096u, (unsigned)q2 + 4096u));
+                            tie = min(tie, (unsigned)q3 + 4096u);
+                            acc = (sdone == 0) ? v0 : acc + v0;
+                            acc = acc + v1;
+                            acc = acc + v2;
+                            acc = acc + v3;
+                            q = q3 + dq;
+                        }
+                        for (; sdone < s_area; ++sdone) {
+                            tie = min(tie, (unsigned)q + 4096u);
+                            const float v = fetch(roff + (int)(q >> 32));
+                            acc = (sdone == 0) ? v : acc + v;
+                            q += dq;
+                        }
+                        exact = tie < 8192u;
+                        qk += dk;
                     }
-                    for (; sdone < s_area; ++sdone) {
-                        tie = min(tie, (unsigned)q + 4096u);
-                        const float v = fetch(roff + (int)(q >> 32));
-                        acc = (sdone == 0) ? v : acc + v;
-                        q += dq;
+                    if (exact) {
+                        for (int sidx = 0; sidx < s_area; ++sidx) {
+                            double ia = frac_index(a0, step_a, (double)(k * s_area + sidx), phi0, dphi, rdphi);
+                            ia = ia < 0.0 ? 0.0 : ia;
+                            ia = ia > nm1 ? nm1 : ia;
+                            const int ri = (int)rint(ia);
+                            const float v = fetch(roff + min(max(ri, 0), N - 1));
+                            acc = (sidx == 0) ? v : acc + v;
+                        }
                     }
-                    exact = tie < 8192u;
+                    float mean_a;
+                    if (area_small_div) {   // RN(acc / s_area): q0 = acc * RN(1/s), one exact residual, one correction
+                        const float m0 = acc * area_rs;
+                        mean_a = fmaf(fmaf(-m0, area_fs, acc), area_rs, m0);
+                    } else {
+                        mean_a = __fdiv_rn(acc, area_fs);
+                    }
+                    float y;
+                    if (VMODE == 2) {
+                        const float df = (float)dd;
+                        y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
+                                       : mean_a;
+                    } else {
+                        y = finish_value<VMODE>(a, (double)mean_a, dd);
+                    }
+                    y = __builtin_amdgcn_fmed3f(y, ylo, yhi);
+                    if (k < klo || k > khi) y = ypad;
+                    if (DBG) {
+                        const double idx = frac_index(a0, wt.step[p], (double)k, phi0, dphi, rdphi);
+                        const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
+                        a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = min(max((int)idx, 0), N - 1);
+                    }
+                    yv[u] = y;
                 }
-                if (exact) {
-                    for (int s = 0; s < s_area; ++s) {
-                        double ia = frac_index(a0, step_a, (double)(k * s_area + s), phi0, dphi, rdphi);
-                        ia = ia < 0.0 ? 0.0 : ia;
-                        ia = ia > nm1 ? nm1 : ia;
-                        const int ri = (int)rint(ia);
-                        const float v = fetch(roff + min(max(ri, 0), N - 1));
-                        acc = (s == 0) ? v : acc + v;
+                const int o_el = out_off + tt * P + kb;
+                if (VS == 4) {
+                    if (out_tile16) {
+                        using H4 = _Float16 __attribute__((ext_vector_type(4)));
+                        H4 hv = {(_Float16)yv[0], (_Float16)yv[1 % VS], (_Float16)yv[2 % VS], (_Float16)yv[3 % VS]};
+                        *reinterpret_cast<H4 *>(out_tile16 + o_el) = hv;
+                    } else {
+                        *reinterpret_cast<float4 *>(out_tile + o_el) = make_float4(yv[0], yv[1 % VS], yv[2 % VS], yv[3 % VS]);
                     }
-                }
-                float mean_a;
-                if (small_div) {        // RN(acc / s_area): q0 = acc * RN(1/s), one exact residual, one correction
-                    const float m0 = acc * rs;
-                    mean_a = fmaf(fmaf(-m0, fs, acc), rs, m0);
                 } else {
-                    mean_a = __fdiv_rn(acc, fs);
+                    if (out_tile16) out_tile16[o_el] = (_Float16)yv[0];
+                    else out_tile[o_el] = yv[0];
                 }
-                float y;
-                if (VMODE == 2) {
-                    const float df = (float)dd;
-                    y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
-                                   : mean_a;
-                } else {
-                    y = finish_value<VMODE>(a, (double)mean_a, dd);
-                }
-                y = __builtin_amdgcn_fmed3f(y, ylo, yhi);
-                if (k < klo || k > khi) y = ypad;
-                if (DBG) {
-                    const double idx = frac_index(a0, step, (double)k, phi0, dphi, rdphi);
-                    const int jj = a.fixed ? p / T : p, tfirst = a.fixed ? p - jj * T : 0;
-                    a.dbg_lo[(((long long)b * P + k) * T + tfirst + tt) * a.Ns + (j0 + jj)] = min(max((int)idx, 0), N - 1);
-                }
-                const int o_el = out_off + tt * P + k;
-                if (out_tile16) out_tile16[o_el] = (_Float16)y;
-                else out_tile[o_el] = y;
             }
         }
     };
@@ -595,12 +615,25 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
             if (work) group(std::false_type{}, std::false_type{}, p, k0);
         }
     }
-    // B2: the area-sampled windows, from the list phase A compacted: one wave per window
+    // B2: the area-sampled windows.  Where most windows of the tile are area-sampled (the dense 0.1-degree scans:
+    // 97 %) every lane takes the window it built in phase A and walks all P outputs: the window's parameters are
+    // read once per 56 outputs, and the lanes of a wave read consecutive points' (or scans') windows.  Where they
+    // are few (0.5-degree scans: the near field only) the list phase A compacted is spread over the lanes, KV
+    // outputs each, so that a handful of windows does not serialise on a handful of lanes.
     const int n_area = s_area > 0 ? s_acount : 0;
-    for (int q = threadIdx.x >> 6; q < n_area; q += kWaves) {
-        const int p = __builtin_amdgcn_readfirstlane(wt.alist[q]);
-        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds)) area_window(std::true_type{}, p);
-        else area_window(std::false_type{}, p);
+    const bool lds_rows = LDSMODE == 1 || (LDSMODE == 2 && span_lds);
+    if (2 * n_area >= nwin) {
+        for (int p = threadIdx.x; p < nwin; p += kThreads) {
+            if (!wt.isarea[p]) continue;
+            if (lds_rows) area_outputs(std::true_type{}, p, 0, P);
+            else area_outputs(std::false_type{}, p, 0, P);
+        }
+    } else {
+        for (int g = threadIdx.x; g < n_area * per_win; g += kThreads) {
+            const int q = (P4 > 0) ? g / P4 : g / per_win;
+            if (lds_rows) area_outputs(std::true_type{}, wt.alist[q], (g - q * per_win) * KV, KV);
+            else area_outputs(std::false_type{}, wt.alist[q], (g - q * per_win) * KV, KV);
+        }
     }
 }
 

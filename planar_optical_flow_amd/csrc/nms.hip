@@ -12,18 +12,19 @@
 // Serial in the number of kept centres and latency bound: reported in
 // microseconds, not GB/s.
 //
-// Round 3, N <= 512 (nms_small_kernel): the serial part no longer costs two workgroup barriers per POINT.
-//   * order by counting: rank of a point = number of points that come before it in the total order (N
-//     comparisons per point, all lanes busy, one barrier) instead of a 45-step bitonic network;
-//   * the N x N suppression relation dist < min_dist is built ONCE, by all waves, as a bit matrix in LDS
-//     (row i = ceil(N/32) words).  No square root: sqrt is monotone and correctly rounded, so
-//     RN(sqrt(s)) < min_dist  <=>  s <= s*, the largest float64 with that property (host, nextafter);
-//   * one wave then walks the kept centres only: the alive set lives in the lanes' registers (one word per
-//     lane), the next kept index is a count-trailing-zeros, a kept centre clears its row from the set: a
-//     handful of instructions and one LDS row read per KEPT centre, no barrier;
-//   * instance ids afterwards, in parallel: the reference lets later kept centres overwrite earlier labels,
-//     so a point's id is that of the LAST kept centre whose row holds it (row & kept, highest bit).
-// 0.26 ms -> measured in profiles/r3_* for 1024 scans x 450 points.
+// Round 3, N <= 512 (nms_wave_kernel): ONE WAVE PER SCAN, no workgroup barrier anywhere.
+//   * lane l owns the sorted positions l, l + 64, ...: up to 8 columns, their centres in registers;
+//   * order: a bitonic network over (score, point index) in LDS in its all-ascending form (the padding to a
+//     power of two is virtual), 45 steps of 4 compare-exchanges per lane for N = 450;
+//   * the greedy walk visits KEPT centres only: the alive set is eight 64-bit ballots in scalar registers, the
+//     next kept index is a count-trailing-zeros; its row of the suppression relation is evaluated on demand by
+//     the 64 lanes (8 exact float64 distance tests each -- no square root: sqrt is monotone and correctly rounded,
+//     so RN(sqrt(s)) < min_dist  <=>  s <= s*, the largest float64 with that property, found on the host with
+//     nextafter) and applied with ballots; the lanes keep the instance id of their columns in registers (later
+//     kept centres overwrite earlier labels, as in the reference);
+//   * round 2's kernel paid two workgroup barriers per POINT (450 x 2 per scan), kept or not: 0.26 ms for 1024
+//     scans; an intermediate round-3 form that built the whole N x N relation up front did four times the distance
+//     tests the walk needs and measured 0.38 ms.
 #include <cmath>
 
 #include "pof_common.h"
@@ -163,129 +164,134 @@ __global__ __launch_bounds__(kThreads) void nms_kernel(NmsArgs a)
 }
 
 constexpr int kSmallMaxN = 512;
-constexpr int kSmallMaxW = kSmallMaxN / 32;
+constexpr int kCols = kSmallMaxN / 64;      // sorted positions per lane
 
 struct NmsSmallArgs {
     NmsArgs a;
     double s2_thr;      // dist < min_dist  <=>  dx*dx + dy*dy <= s2_thr
 };
 
-__global__ __launch_bounds__(kThreads) void nms_small_kernel(NmsSmallArgs A)
+__device__ __forceinline__ void nms_lds_order()
 {
-    extern __shared__ __align__(16) unsigned char smem[];
-    const NmsArgs &a = A.a;
-    const int N = a.N, W = (N + 31) >> 5;
-    double *s_key = reinterpret_cast<double *>(smem);          // [N] score in sorted order
-    double *s_x = s_key + kSmallMaxN;                          // [N] centre, sorted order
-    double *s_y = s_x + kSmallMaxN;
-    double *s_raw = s_y + kSmallMaxN;                          // [N] score by point index
-    int *s_ord = reinterpret_cast<int *>(s_raw + kSmallMaxN);  // [N] point index of sorted position
-    unsigned *s_kept = reinterpret_cast<unsigned *>(s_ord + kSmallMaxN);   // [W] kept set
-    int *s_base = reinterpret_cast<int *>(s_kept + kSmallMaxW);            // [W] kept centres before word w
-    unsigned *s_mat = reinterpret_cast<unsigned *>(s_base + kSmallMaxW);   // [N][W] suppression relation
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(64) void nms_wave_kernel(NmsSmallArgs A)
+{
+    __shared__ double s_key[kSmallMaxN];     // score, sorted
+    __shared__ double s_x[kSmallMaxN], s_y[kSmallMaxN];
+    __shared__ int s_ord[kSmallMaxN];        // point index of a sorted position
+    __shared__ int s_kept[kSmallMaxN];       // sorted positions of the kept centres, in order
+    const NmsArgs &a = A.a;
+    const int N = a.N, b = blockIdx.x, lane = threadIdx.x;
     const float *r = a.ranges + (long long)b * N;
     const double *cls = a.pred_cls + (long long)b * N;
     const double *reg = a.pred_reg + (long long)b * N * 2;
-    for (int i = tid; i < N; i += kThreads) s_raw[i] = cls[i];
-    __syncthreads();
-    // rank in the total order (score, point index) descending = position in the sorted sequence
-    for (int i = tid; i < N; i += kThreads) {
-        const double ki = s_raw[i];
-        int rank = 0;
-        for (int j = 0; j < N; ++j) {
-            const double kj = s_raw[j];
-            rank += ((kj > ki) || (kj == ki && j > i)) ? 1 : 0;
-        }
-        // a NaN score compares false both ways: it would collide with other ranks; give NaNs the tail in index order
-        if (ki != ki) {
-            rank = 0;
-            for (int j = 0; j < N; ++j) rank += (s_raw[j] == s_raw[j] || j > i) ? 1 : 0;
-        }
-        s_ord[rank] = i;
-        s_key[rank] = ki;
-        const double ty = (double)r[i] + reg[2 * i + 1];
-        const double tphi = atan2(reg[2 * i], ty);
-        const double dphi = tphi + a.tab[i];
-        const double dr = ty / cos(tphi);
-        double sn, cs;
-        sincos(dphi, &sn, &cs);
-        s_x[rank] = dr * cs;
-        s_y[rank] = dr * sn;
+    for (int i = lane; i < N; i += 64) {
+        s_key[i] = cls[i];
+        s_ord[i] = i;
     }
-    int32_t *inst = a.instance_mask + (long long)b * N;
-    __syncthreads();
-    // suppression relation: word (i, w) = bits j = 32 w .. of  (dx*dx + dy*dy <= s2_thr)
-    for (int e = tid; e < N * W; e += kThreads) {
-        const int i = e / W, w = e - i * W;
-        const double xi = s_x[i], yi = s_y[i];
-        unsigned bits = 0;
-        const int j0 = 32 * w, jn = min(32, N - j0);
-        for (int u = 0; u < jn; ++u) {
-            const double dx = xi - s_x[j0 + u], dy = yi - s_y[j0 + u];
-            bits |= (dx * dx + dy * dy <= A.s2_thr ? 1u : 0u) << u;
-        }
-        s_mat[e] = bits;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        // the greedy walk, one wave, no barrier: lane w holds word w of the alive set
-        const int lane = tid;
-        unsigned alive = 0, kept = 0;
-        if (lane < W) alive = (lane == W - 1 && (N & 31)) ? ((1u << (N & 31)) - 1u) : 0xffffffffu;
-        int w = 0;
-        unsigned lowmask = 0xffffffffu;         // bits of word w not yet passed
-        while (w < W) {
-            const unsigned m = (unsigned)__builtin_amdgcn_readlane((int)alive, w) & lowmask;
-            if (m == 0) {
-                ++w;
-                lowmask = 0xffffffffu;
-                continue;
+    nms_lds_order();
+    // bitonic network, all-ascending form, on the total order "u comes before v": (score, point index)
+    // descending; a NaN score comes after every number (NumPy sorts NaNs to the end of the ascending order, the
+    // reference reverses it -- its NaNs lead; either way the order among NaNs is by point index and a scan with
+    // NaN scores is not a comparable case)
+    int npad = 1;
+    while (npad < N) npad <<= 1;
+    const int half = npad >> 1;
+    auto cmpx = [&](int lo, int hi) {
+        if (hi < N) {
+            const double kl = s_key[lo], kh = s_key[hi];
+            const int ol = s_ord[lo], oh = s_ord[hi];
+            const bool nl = kl != kl, nh = kh != kh;
+            const bool hi_first = (!nh && nl) || (nl == nh && ((kh > kl) || (!(kl > kh) && oh > ol)));
+            if (hi_first) {
+                s_key[lo] = kh;
+                s_key[hi] = kl;
+                s_ord[lo] = oh;
+                s_ord[hi] = ol;
             }
-            const int bit = __builtin_ctz(m);
-            const int idx = 32 * w + bit;
-            const unsigned row = lane < W ? s_mat[idx * W + lane] : 0u;
-            alive &= ~row;                       // everything within min_dist of the kept centre, itself included
-            if (lane == w) kept |= 1u << bit;
-            lowmask = bit == 31 ? 0u : (0xffffffffu << (bit + 1));
         }
-        if (lane < W) s_kept[lane] = kept;
-        // kept centres before each word (exclusive prefix of the popcounts)
-        int c = lane < W ? __builtin_popcount(kept) : 0, pre = c;
-#pragma unroll
-        for (int o = 1; o < kSmallMaxW; o <<= 1) {
-            const int v = __shfl_up(pre, o, 64);
-            if (lane >= o) pre += v;
+    };
+    for (int k = 2; k <= npad; k <<= 1) {
+        const int hk = k >> 1;
+        for (int t = lane; t < half; t += 64) {
+            const int blk = t / hk, off = t - blk * hk;
+            cmpx(blk * k + off, blk * k + k - 1 - off);
         }
-        if (lane < W) s_base[lane] = pre - c;
-        if (lane == W - 1) a.num_det[b] = pre;
+        nms_lds_order();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int t = lane; t < half; t += 64) {
+                const int lo = 2 * j * (t / j) + (t % j);
+                cmpx(lo, lo + j);
+            }
+            nms_lds_order();
+        }
     }
-    __syncthreads();
+    // centres of this lane's columns (sorted positions lane + 64 c)
+    double xr[kCols], yr[kCols];
+    int inst_id[kCols];
+    unsigned long long alive[kCols];         // wave-uniform ballots: column c of lane l alive <=> bit l
+#pragma unroll
+    for (int c = 0; c < kCols; ++c) {
+        const int i = lane + 64 * c;
+        xr[c] = yr[c] = 0.0;
+        inst_id[c] = 0;
+        if (i < N) {
+            const int src = s_ord[i];
+            const double ty = (double)r[src] + reg[2 * src + 1];
+            const double tphi = atan2(reg[2 * src], ty);
+            const double dphi = tphi + a.tab[src];
+            const double dr = ty / cos(tphi);
+            double sn, cs;
+            sincos(dphi, &sn, &cs);
+            xr[c] = dr * cs;
+            yr[c] = dr * sn;
+            s_x[i] = xr[c];
+            s_y[i] = yr[c];
+        }
+        alive[c] = __ballot(i < N);
+    }
+    nms_lds_order();
+    // greedy walk over the kept centres
+    int nkept = 0;
+    while (true) {
+        int i = -1;
+#pragma unroll
+        for (int c = kCols - 1; c >= 0; --c)
+            if (alive[c] != 0ull) i = 64 * c + __builtin_ctzll(alive[c]);
+        if (i < 0) break;
+        const double xi = s_x[i], yi = s_y[i];
+        ++nkept;
+        if (lane == 0) s_kept[nkept - 1] = i;
+#pragma unroll
+        for (int c = 0; c < kCols; ++c) {
+            const double dx = xi - xr[c], dy = yi - yr[c];
+            const bool hit = (lane + 64 * c < N) && (dx * dx + dy * dy <= A.s2_thr);
+            alive[c] &= ~__ballot(hit);
+            if (hit) inst_id[c] = nkept;
+            // the kept centre leaves the set even when it is not within min_dist of itself (NaN centre)
+            if ((i >> 6) == c) alive[c] &= ~(1ull << (i & 63));
+        }
+    }
+    nms_lds_order();
+    int32_t *inst = a.instance_mask + (long long)b * N;
+#pragma unroll
+    for (int c = 0; c < kCols; ++c) {
+        const int i = lane + 64 * c;
+        if (i < N) inst[s_ord[i]] = inst_id[c];
+    }
     double *oxy = a.det_xy + (long long)b * N * 2;
     double *ocl = a.det_cls + (long long)b * N;
-    for (int j = tid; j < N; j += kThreads) {
-        // id of a kept centre = its 1-based position among the kept ones; a point carries the id of the LAST kept
-        // centre whose row holds it (later ids overwrite earlier ones in the reference); the relation is symmetric,
-        // so that is the highest bit of row_j & kept
-        int id = 0;
-        for (int w = W - 1; w >= 0; --w) {
-            const unsigned v = s_mat[j * W + w] & s_kept[w];
-            if (v) {
-                const int hb = 31 - __builtin_clz(v);
-                id = s_base[w] + __builtin_popcount(s_kept[w] & ((hb == 31) ? 0xffffffffu : ((1u << (hb + 1)) - 1u)));
-                break;
-            }
-        }
-        inst[s_ord[j]] = id;
-        const int wj = j >> 5, bj = j & 31;
-        if ((s_kept[wj] >> bj) & 1u) {
-            const int pos = s_base[wj] + __builtin_popcount(s_kept[wj] & ((1u << bj) - 1u));
-            oxy[2 * pos] = s_x[j];
-            oxy[2 * pos + 1] = s_y[j];
-            ocl[pos] = s_key[j];
-        }
+    for (int k = lane; k < nkept; k += 64) {
+        const int i = s_kept[k];
+        oxy[2 * k] = s_x[i];
+        oxy[2 * k + 1] = s_y[i];
+        ocl[k] = s_key[i];
     }
+    if (lane == 0) a.num_det[b] = nkept;
 }
 
 // largest float64 s with RN(sqrt(s)) < r (the reference compares the rounded distance with min_dist)
@@ -339,10 +345,7 @@ extern "C" int pof_nms_predicted_center(const float *ranges, const double *tab, 
         NmsSmallArgs A;
         A.a = a;
         A.s2_thr = nms_sq_threshold(min_dist);
-        const int W = (N + 31) / 32;
-        const size_t lds_s = (size_t)kSmallMaxN * (4 * sizeof(double) + sizeof(int)) + 2 * kSmallMaxW * sizeof(int) +
-                             (size_t)N * W * sizeof(unsigned);
-        nms_small_kernel<<<B, kThreads, lds_s, pof_stream(stream)>>>(A);
+        nms_wave_kernel<<<B, 64, 0, pof_stream(stream)>>>(A);
         POF_CHECK_LAUNCH();
         return POF_OK;
     }

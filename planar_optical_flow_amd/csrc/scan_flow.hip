@@ -92,7 +92,7 @@ __device__ __forceinline__ double opaque_zero()
     return z;
 }
 
-__device__ void motion_params(int kind, const double *o0, const double *o1, double sA, double cA,
+__device__ __forceinline__ void motion_params(int kind, const double *o0, const double *o1, double sA, double cA,
                               double sB, double cB, double *mot)
 {
     const double tx = o1[0] - o0[0], ty = o1[1] - o0[1];
@@ -257,12 +257,13 @@ __device__ __forceinline__ void params_sincos(double x, double *sn, double *cs)
         n = -n;
     }
     const double s = poly_sin(y0, y1), c = poly_cos(y0, y1);
-    switch (n & 3) {
-        case 0: *sn = s; *cs = c; break;
-        case 1: *sn = c; *cs = -s; break;
-        case 2: *sn = -s; *cs = -c; break;
-        default: *sn = -c; *cs = s; break;
-    }
+    // quadrant: 0 (s, c), 1 (c, -s), 2 (-s, -c), 3 (-c, s) -- as selects (a switch becomes a table in scratch)
+    const bool odd = (n & 1) != 0;
+    double ss = odd ? c : s, cc = odd ? s : c;
+    if (n & 2) ss = -ss;
+    if ((n + 1) & 2) cc = -cc;
+    *sn = ss;
+    *cs = cc;
 }
 
 // AP: pointer to the arguments -- a plain pointer to a by-value kernel argument, or a constant-address-space
@@ -298,27 +299,32 @@ __device__ __forceinline__ bool det_is_far(double cx, double cy, double sd)
     return !(fabs(cx) + fabs(cy) < 100.0) || !(sd <= 400.0);
 }
 
-// number of params jobs of a batch: two per sample
+// number of params jobs of a batch: kInline (8) lanes per sample
 __host__ __device__ inline int params_job_count(int B, bool have_dets)
 {
     (void)have_dets;
-    return 2 * B;
+    return kInline * B;
 }
 
-// Params job t: lane `which` = t & 1 of sample t >> 1.  The lane evaluates motion angle `which` (the partner lane
-// t ^ 1 holds the other one; lane 0 combines them) and then the sample's detections which, which + 2, ... -- one
-// sincos per pass of ONE loop -- into the sample's record: the float64 part, the flat image, and for samples with
-// more than kInline detections all rows of the CSR table.
-// Round 3: two lanes per SAMPLE.  Round 2 used one lane per angle and per inline detection slot (10 lanes per
-// sample, one sincos each): five times the wave slots for the same work, held through the same two dependent
-// memory round trips -- with eight batches per launch those blocks took a fifth of the chip's wave slots for the
-// length of their chains (measured: 1.0 us per 4096-scan step).  One loop with one sincos call site and nothing
-// carried round it but indices keeps the job inside the 64 registers of the streaming waves without scratch.
-template <bool FALLBACK, typename AP>
+// Params job t: lane `slot` = t & 7 of sample t >> 3.  Slots 0 and 1 evaluate the two motion angles (slot 0 combines
+// them); then slot s evaluates detections s, s + 8, ... -- one sincos per pass of ONE loop (a single call site, and
+// nothing carried round the loop but indices: the job fits the 64 registers of the streaming waves without
+// scratch) -- into the sample's record.
+// What decides the layout is the STORE pattern, not the arithmetic.  The params blocks share their CUs' memory
+// pipes with streaming waves that are bound by exactly those pipes; a store instruction whose 64 lanes hit 64
+// different cache lines costs 64 line transactions.  Round 3's first form (two lanes per sample, every lane
+// writing its sample's fields one by one) issued ~2 400 line transactions per wave, a third of what the streaming
+// waves of the same CU need for a whole batch, and measured 1.2 us per 4096-scan step (2.2 us at 8 detections per
+// sample).  Here the eight slot lanes of a sample write its eight 16-byte screen entries, its eight 16-byte
+// centres and its class / far bytes as contiguous runs (one line each), slot 0 writes the header and the float64
+// motion as 16-byte stores: ~11 store instructions per wave of 8 samples, <= 8 lines each.  WRITE_F64: also the
+// float64 part that only the per-sample kernels read (the flat kernel needs the 384-byte image and, for crowded
+// samples, the CSR table).
+template <bool FALLBACK, bool WRITE_F64, typename AP>
 __device__ __forceinline__ void params_work(AP a, int t)
 {
-    if (t >= 2 * a->B) return;                 // whole lane pairs: 2 * B is even
-    const int b = t >> 1, which = t & 1;
+    if (t >= kInline * a->B) return;               // whole groups of 8 lanes
+    const int b = t >> 3, slot = t & 7;
     double *rec = a->ws_rec + (long long)b * kRecStride;
     unsigned char *img = reinterpret_cast<unsigned char *>(rec + kRecImg);
     int d0 = 0, cnt = 0;
@@ -326,15 +332,16 @@ __device__ __forceinline__ void params_work(AP a, int t)
         d0 = a->det_offsets[b];
         cnt = a->det_offsets[b + 1] - d0;
     }
-    // pass 0: the motion angle; pass p >= 1: detection which + 2 (p - 1)
-    const int npass = 1 + (cnt - which + 1) / 2;
+    // pass 0: the motion angle (slots 0, 1); pass p >= 1: detection slot + 8 (p - 1)
+    const int npass = 1 + (cnt - slot + kInline - 1) / kInline;
 #pragma unroll 1
-    for (int pass = a->flow ? 0 : 1; pass < npass; ++pass) {
-        const int idx = which + 2 * (pass - 1);
-        double ang, dr = 0.0;
+    for (int pass = a->flow ? 0 : 1; pass < max(npass, 1); ++pass) {
+        const int idx = slot + kInline * (pass - 1);
+        const bool active = pass == 0 ? slot < 2 : idx < cnt;
+        double ang = 0.0, dr = 0.0;
         if (pass == 0) {
-            ang = motion_angle(a->flow_kind, which, a->odom0 + 3 * b, a->odom1 + 3 * b);
-        } else {
+            if (active) ang = motion_angle(a->flow_kind, slot, a->odom0 + 3 * b, a->odom1 + 3 * b);
+        } else if (active) {
             dr = a->det_rphi[2 * (d0 + idx)];
             ang = a->det_rphi[2 * (d0 + idx) + 1];
         }
@@ -343,17 +350,22 @@ __device__ __forceinline__ void params_work(AP a, int t)
         if (pass == 0) {
             // every lane of the wave is here together (pass 0 is each lane's first): the partner's angle
             const double s_o = __shfl_xor(sn, 1, 64), c_o = __shfl_xor(cs, 1, 64);
-            if (which == 0) {
-                float *hf = reinterpret_cast<float *>(img);
+            if (slot == 0) {
+                // straight into the image's float64 motion (a private array here is indexed by the flow kind
+                // after inlining and lands in scratch); the float32 header and the float64 part are copies of it
                 double *m64 = reinterpret_cast<double *>(img + kImgMot);
-                motion_params(a->flow_kind, a->odom0 + 3 * b, a->odom1 + 3 * b, sn, cs, s_o, c_o, rec);
+                motion_params(a->flow_kind, a->odom0 + 3 * b, a->odom1 + 3 * b, sn, cs, s_o, c_o, m64);
+                m64[7] = (double)cnt;
+                float4 *hf = reinterpret_cast<float4 *>(img);
+                hf[0] = make_float4((float)m64[0], (float)m64[1], (float)m64[2], (float)m64[3]);
+                hf[1] = make_float4((float)m64[4], (float)m64[5], (float)m64[6], __int_as_float(cnt));
+                if (WRITE_F64) {
+                    double2 *r2 = reinterpret_cast<double2 *>(rec);
 #pragma unroll
-                for (int k = 0; k < 7; ++k) {
-                    hf[k] = (float)rec[k];
-                    m64[k] = rec[k];
+                    for (int k = 0; k < 4; ++k) r2[k] = make_double2(m64[2 * k], m64[2 * k + 1]);
                 }
             }
-        } else {
+        } else if (active) {
             const unsigned cl = a->det_cls[d0 + idx] > 1 ? 2u : (unsigned)a->det_cls[d0 + idx];
             double w[kDetStride];
             w[0] = dr * cs;
@@ -363,39 +375,43 @@ __device__ __forceinline__ void params_work(AP a, int t)
             w[4] = (double)(cl == 0 ? a->lb0 : (cl == 1 ? a->lb1 : a->lb2));
             w[5] = cl == 0 ? a->sa0 : (cl == 1 ? a->sa1 : a->sa2);   // dist <  assoc radius <=>  s <= w[5]
             if (idx < kInline) {
-                double *r = rec + 8 + idx * kDetStride;
-#pragma unroll
-                for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
                 const bool far = det_is_far(w[0], w[1], w[3]);
                 reinterpret_cast<float4 *>(img + kImgScreen)[idx] =
                     make_float4((float)w[0], (float)w[1], far ? INFINITY : -(float)w[3], (float)(w[5] - w[3]));
                 reinterpret_cast<double2 *>(img + kImgCtr)[idx] = make_double2(w[0], w[1]);
-                img[32 + idx] = (unsigned char)cl;          // byte stores: nothing carried round the loop
+                img[32 + idx] = (unsigned char)cl;
                 img[40 + idx] = far ? 1 : 0;
+                if (WRITE_F64) {
+                    double2 *r2 = reinterpret_cast<double2 *>(rec + 8 + idx * kDetStride);
+                    r2[0] = make_double2(w[0], w[1]);
+                    r2[1] = make_double2(w[2], w[3]);
+                    r2[2] = make_double2(w[4], w[5]);
+                }
             }
             if (cnt > kInline) {
-                double *r = a->ws_det + (long long)(d0 + idx) * kDetStride;
-#pragma unroll
-                for (int c = 0; c < kDetStride; ++c) r[c] = w[c];
+                double2 *r2 = reinterpret_cast<double2 *>(a->ws_det + (long long)(d0 + idx) * kDetStride);
+                r2[0] = make_double2(w[0], w[1]);
+                r2[1] = make_double2(w[2], w[3]);
+                r2[2] = make_double2(w[4], w[5]);
             }
         }
     }
-    if (which == 0) {
-        rec[7] = (double)cnt;
-        reinterpret_cast<double *>(img + kImgMot)[7] = (double)cnt;
+    if (!a->flow && slot == 0) {
+        // no motion pass: the count still belongs in the header (and in the float64 copies)
         reinterpret_cast<int *>(img)[7] = cnt;
+        reinterpret_cast<double *>(img + kImgMot)[7] = (double)cnt;
+        if (WRITE_F64) rec[7] = (double)cnt;
     }
-    if (!a->det_offsets) return;
-    // unused inline slots: the null screen entry (never the minimum), not far
-    for (int idx = cnt + which; idx < kInline; idx += 2) {
-        reinterpret_cast<float4 *>(img + kImgScreen)[idx] = make_float4(0.0f, 0.0f, INFINITY, 0.0f);
-        img[40 + idx] = 0;
+    if (a->det_offsets && slot >= cnt) {
+        // unused inline slot: the null screen entry (never the minimum), not far
+        reinterpret_cast<float4 *>(img + kImgScreen)[slot] = make_float4(0.0f, 0.0f, INFINITY, 0.0f);
+        img[40 + slot] = 0;
     }
 }
 
 __global__ __launch_bounds__(256) void scan_params_kernel(PreArgs a)
 {
-    params_work<true>(&a, blockIdx.x * blockDim.x + threadIdx.x);
+    params_work<true, true>(&a, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // A value that is the same in every lane, moved to scalar registers.
@@ -1167,7 +1183,7 @@ __global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L,
             for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
             const auto *pa = reinterpret_cast<const __attribute__((address_space(4))) PreArgs *>(
                 ka + kFlatArgsKernargBytes + offsetof(ParamsMulti, p) + (size_t)k * sizeof(PreArgs));
-            params_work<false>(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
+            params_work<false, false>(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
 #endif
             return;
         }
@@ -1283,7 +1299,7 @@ __global__ __launch_bounds__(kThreads, 8) void scan_preprocess_chain_kernel(PreA
     // params rows LAST: measured 20.2 us per step against 22.7 us with the params rows first
     // (dispatched first, their long sincos chains hold CU slots the streaming rows need)
     if ((int)blockIdx.y >= main_rows) {
-        if (blockIdx.x == 0) params_work<false>(&nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
+        if (blockIdx.x == 0) params_work<false, true>(&nx, ((int)blockIdx.y - main_rows) * kThreads + threadIdx.x);
         return;
     }
     scan_main<OutT, PTS, SPB>(a, blockIdx.y);

@@ -52,9 +52,10 @@ class PointNet(nn.Module):
         self.conv4 = _pointwise(128, 1024)
 
     gemm_pointwise = True   # GPU inference: the 1x1 convolutions as library GEMMs over [B*n, C]
+    train_pointwise = False  # the same form in training mode (autograd through F.linear / BatchNorm on [B*n, C])
 
     def forward(self, x):  # x [B, C, n]
-        if x.is_cuda and self.gemm_pointwise and not self.training:
+        if x.is_cuda and self.gemm_pointwise and (self.train_pointwise or not self.training):
             return self.forward_points(x.permute(0, 2, 1))
         x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
         return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
@@ -97,8 +98,9 @@ class BoundingBoxRegressor(PointNet):
         return _model_eval_fn(model, batch_data)
 
     def forward(self, x):  # x [B, n, C]
-        x = self.backbone.forward_points(x) if (x.is_cuda and self.backbone.gemm_pointwise and not self.training) \
-            else self.backbone(x.permute(0, 2, 1))
+        bb = self.backbone
+        x = bb.forward_points(x) if (x.is_cuda and bb.gemm_pointwise and (bb.train_pointwise or not self.training)) \
+            else bb(x.permute(0, 2, 1))
         x = self.fc2(self.fc1(x))
         if self.dropout > 0.0:
             x = F.dropout(x, p=self.dropout, training=self.training)

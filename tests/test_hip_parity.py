@@ -732,7 +732,15 @@ def test_params_sincos_domain(ops):
     o2 = {"flow": torch.zeros((64, 450, 2), dtype=torch.float64, device=DEV),
           "target_cls": torch.zeros((64, 450), dtype=torch.int64, device=DEV)}
     slot = {"scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det, "workspace": ws, "out": o2}
-    ops.scan_preprocess_multi([], tab, next_batches=[slot], want=want, out_dtype=torch.float64)
+    # the params blocks INSIDE the flat kernel: a launch that streams another batch and evaluates this one's params
+    sb2 = synth.make_batch(seed=92, B=32, T=2)
+    det2 = csr(ops, sb2)
+    other = {"scans": T(sb2.scans), "odom0": T(sb2.odom0), "odom1": T(sb2.odom1), "dets": det2,
+             "workspace": torch.empty(ops.scan_preprocess_workspace_bytes(32, det2.rphi.shape[0]), dtype=torch.uint8, device=DEV),
+             "out": {"flow": torch.zeros((32, 450, 2), dtype=torch.float64, device=DEV),
+                     "target_cls": torch.zeros((32, 450), dtype=torch.int64, device=DEV)}}
+    ops.scan_preprocess_multi([], tab, next_batches=[other], want=want, out_dtype=torch.float64)
+    ops.scan_preprocess_multi([other], tab, next_batches=[slot], want=want, out_dtype=torch.float64)
     ops.scan_preprocess_multi([slot], tab, want=want, out_dtype=torch.float64)
     f2 = o2["flow"].cpu().numpy()
     assert np.isnan(f2[7]).all()

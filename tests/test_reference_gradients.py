@@ -103,34 +103,39 @@ def test_spatial_drow_training_step_equals_reference(golden):
     loss, tb, _ = eval_utils.model_fn_obj_det(m, {"input": g["sd_x"], "target_flow_cls": g["sd_cls"],
                                                   "target_flow_reg": g["sd_reg"]})
     loss.backward()
-    np.testing.assert_allclose([float(loss.detach()), tb["cls_loss"], tb["reg_loss"]], g["sd_loss"], rtol=2e-4)
+    np.testing.assert_allclose([float(loss.detach()), tb["cls_loss"], tb["reg_loss"]], g["sd64_loss"], rtol=1e-5)
     names = [k for k, _ in m.named_parameters()]
     assert names == list(g["sd_names"])
     params = dict(m.named_parameters())
-    # every parameter: signed sum and absolute sum of its gradient.  Bar: 2e-3 of the gradient's own absolute sum
-    # plus 1e-6 of the largest one -- a convolution bias in front of a BatchNorm has a mathematically zero
-    # gradient, what either side holds there is round-off (2e-5 in the reference, 4e-6 here)
-    top = float(g["sd_gabs"].max())
+    # Yardstick: the fixture also holds the gradients of the reference's modules run in float64.  The reference's own
+    # float32 gradients are up to 7e-4 (relative to the tensor's scale) away from those -- train-mode BatchNorm
+    # backward cancels means through ten layers -- so the bar for the device is: its distance from the float64
+    # gradients is within 3x the reference's float32 distance, or within 1e-4 of the tensor's scale.
+    top = float(g["sd64_gabs"].max())
     for i, k in enumerate(names):
         gr = params[k].grad.double()
-        ab = float(g["sd_gabs"][i])
-        tol = 2e-3 * ab + 1e-6 * top
-        assert abs(float(gr.abs().sum()) - ab) <= tol, (k, float(gr.abs().sum()), ab)
-        assert abs(float(gr.sum()) - float(g["sd_gsum"][i])) <= tol, (k, float(gr.sum()), g["sd_gsum"][i])
+        ab64, ab32 = float(g["sd64_gabs"][i]), float(g["sd_gabs"][i])
+        s64, s32 = float(g["sd64_gsum"][i]), float(g["sd_gsum"][i])
+        tol_abs = 3.0 * abs(ab32 - ab64) + 1e-4 * ab64 + 1e-9 * top
+        tol_sum = 3.0 * abs(s32 - s64) + 1e-4 * ab64 + 1e-9 * top
+        assert abs(float(gr.abs().sum()) - ab64) <= tol_abs, (k, float(gr.abs().sum()), ab64, ab32)
+        assert abs(float(gr.sum()) - s64) <= tol_sum, (k, float(gr.sum()), s64, s32)
     # whole tensors
     for key in g.files:
-        if not key.startswith("sd_grad_"):
+        if not key.startswith("sd64_grad_"):
             continue
-        name = key[len("sd_grad_"):]
+        name = key[len("sd64_grad_"):]
         head = name.endswith("_head")
         name = name[:-5] if head else name
         match = [k for k in names if k.replace(".", "_") == name]
         assert len(match) == 1, name
         gr = params[match[0]].grad
-        want = g[key]
-        got = (gr[:want.shape[0]] if head else gr).detach().cpu().numpy()
-        err = float(np.abs(got.astype(np.float64) - want).max())
-        assert err <= 1e-3 * float(np.abs(want).max()) + 1e-8 * top, (match[0], err, float(np.abs(want).max()))
+        want64, ref32 = g[key], g["sd_grad_" + key[len("sd64_grad_"):]]
+        got = (gr[:want64.shape[0]] if head else gr).detach().cpu().numpy().astype(np.float64)
+        scale = float(np.abs(want64).max())
+        err = float(np.abs(got - want64).max())
+        ref_err = float(np.abs(ref32.astype(np.float64) - want64).max())
+        assert err <= 3.0 * ref_err + 1e-4 * scale + 1e-12 * top, (match[0], err, ref_err, scale)
     bufs = dict(m.named_buffers())
     close(bufs["conv_block_1.0.1.running_mean"], g["sd_run_mean_b1"], 1e-4, "running mean")
     close(bufs["conv_block_4.1.1.running_var"], g["sd_run_var_b4"], 1e-4, "running var")

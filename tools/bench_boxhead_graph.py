@@ -11,8 +11,10 @@ from planar_optical_flow_amd.graph_step import GraphedTrainStep
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "graph"
 per = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+pointwise = len(sys.argv) > 3 and sys.argv[3] == "points"
 torch.manual_seed(4)
 model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).cuda().train()
+model.backbone.train_pointwise = pointwise
 optim = Optim(model, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
 x = torch.randn((per, 64, 3), device="cuda") * 0.3
 y = torch.randn((per, 3), device="cuda") * 0.3
@@ -32,4 +34,5 @@ t0 = time.perf_counter()
 n = 100
 for _ in range(n): step()
 torch.cuda.synchronize()
-print("box head train step [%s] batch %d: %.3f ms" % (mode, per, (time.perf_counter() - t0) / n * 1e3))
+print("box head train step [%s, %s] batch %d: %.3f ms" % (mode, "points-major GEMMs" if pointwise else "Conv1d modules", per,
+                                                         (time.perf_counter() - t0) / n * 1e3))

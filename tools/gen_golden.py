@@ -180,7 +180,8 @@ def gen_gradients():
       A10  _SpatialAttention.forward         d x, d x_template, d emb (both conv outputs), d conv weight / bias /
                                              BatchNorm affine                     dr_spaam.py:163-217
       N2   SpatialDROW train-mode step       loss + every parameter's gradient as (sum, abs-sum) and a few whole
-           (model_fn_obj_det)                tensors                              dr_spaam.py:41-121, 220-277
+           (model_fn_obj_det)                tensors, in float32 (the reference as it runs) and with its
+                                             modules in float64 (the yardstick)   dr_spaam.py:41-121, 220-277
            Prototype train-mode step         loss (EPE) + gradient summaries      prototype.py:57-109
     """
     from src.depracted.model import prototype as proto
@@ -252,6 +253,26 @@ def gen_gradients():
         g["sd_grad_" + k.replace(".", "_")] = params[k].grad.numpy()
     g["sd_grad_conv_block_3_0_0_weight_head"] = params["conv_block_3.0.0.weight"].grad[:8].numpy()
     g["sd_grad_gate_conv_0_weight_head"] = params["gate.conv.0.weight"].grad[:4].numpy()
+    # the same step with the reference's modules in float64 (its loss adapter casts to float32, so the adapter's
+    # formulas -- eval_utils.py:51-75 -- are applied to the float64 outputs here): how far the reference's OWN
+    # float32 gradients are from the exact ones is the yardstick for the device's
+    torch.manual_seed(3)
+    m64 = spaam.SpatialDROW(num_scans=5, num_pts=56, alpha=0.5, window_size=11, pedestrian_only=True).double()
+    m64.train()
+    pc64, pr64, _ = m64(xin.double())
+    tcl, trg = torch.from_numpy(tc).long().view(-1), torch.from_numpy(tr).double().view(-1, 2)
+    cl64 = m64.cls_loss(torch.sigmoid(pc64.view(-1, 1).squeeze(-1)), tcl.double(), reduction="mean")
+    fg = tcl.ne(0)
+    rg64 = torch.sqrt(torch.sum(torch.nn.functional.mse_loss(pr64.view(-1, 2)[fg], trg[fg], reduction="none"), dim=1)).mean()
+    (cl64 + rg64).backward()
+    g["sd64_loss"] = np.array([float((cl64 + rg64).detach()), float(cl64.detach()), float(rg64.detach())])
+    p64 = dict(m64.named_parameters())
+    g["sd64_gsum"] = np.array([float(p.grad.sum()) for _, p in m64.named_parameters()])
+    g["sd64_gabs"] = np.array([float(p.grad.abs().sum()) for _, p in m64.named_parameters()])
+    for k in whole:
+        g["sd64_grad_" + k.replace(".", "_")] = p64[k].grad.numpy()
+    g["sd64_grad_conv_block_3_0_0_weight_head"] = p64["conv_block_3.0.0.weight"].grad[:8].numpy()
+    g["sd64_grad_gate_conv_0_weight_head"] = p64["gate.conv.0.weight"].grad[:4].numpy()
     bufs = dict(mref.named_buffers())
     g["sd_run_mean_b1"] = bufs["conv_block_1.0.1.running_mean"].numpy()
     g["sd_run_var_b4"] = bufs["conv_block_4.1.1.running_var"].numpy()

@@ -47,16 +47,18 @@ torch.cuda.synchronize()
 assert t.sum().item() == 4.0
 
 # a whole optimisation step -- SyncBatchNorm collectives, the gradient all-reduce (gradients are views of the flat
-# bucket), Adam -- captured as ONE hipGraph and replayed; against the eager single-process step with stock
-# BatchNorm.  The replayed steps must not synchronise with the host (sync debug mode "error" raises if they do).
+# bucket), Adam -- captured as ONE hipGraph and replayed; against the same step issued eagerly (same modules, same
+# collectives).  The replayed steps must not synchronise with the host (sync debug mode "error" raises if they do).
 from planar_optical_flow_amd.graph_step import GraphedTrainStep, make_capturable     # noqa: E402
 torch.manual_seed(6)
 gm = get_model(cfg).cuda()
 pd.convert_sync_batchnorm(gm).train()
 torch.manual_seed(6)
-em = get_model(cfg).cuda().train()
+em = get_model(cfg).cuda()                      # the eager twin: the same modules, collectives issued eagerly
+pd.convert_sync_batchnorm(em).train()
 gopt = torch.optim.Adam(gm.parameters(), lr=1e-3, amsgrad=True)
 eopt = torch.optim.Adam(em.parameters(), lr=1e-3, amsgrad=True)
+ered = pd.GradientAllReduce(em, always=True)
 make_capturable(gopt)
 red2 = pd.GradientAllReduce(gm, always=True)
 gstep = GraphedTrainStep(gm, gopt, {"input": x, "target": y}, reducer=red2)
@@ -70,15 +72,19 @@ for it in range(4):
     torch.cuda.set_sync_debug_mode("error")
     gl = gstep({"input": xb, "target": yb})
     torch.cuda.set_sync_debug_mode("default")
-    eopt.zero_grad()
+    eopt.zero_grad(set_to_none=False)
     el = em.loss_fn(em(xb), yb)
     el.backward()
+    ered()
     eopt.step()
     worst_loss = max(worst_loss, abs(gl.item() - el.item()) / max(abs(el.item()), 1e-6))
     assert red2.stop_requested() == (it == 2), it       # the flag of THIS step's all-reduce, read after it
-assert worst_loss < 1e-3, worst_loss
-wdiff = max((p - q).abs().max().item() for p, q in zip(gm.parameters(), em.parameters()))
-assert wdiff < 1e-4, wdiff
+assert worst_loss < 1e-5, worst_loss
+# weights after four Adam steps.  A bias in front of a BatchNorm has a mathematically zero gradient; what a run
+# holds there is round-off, which Adam normalises to steps of +-lr (the losses above do not depend on it): left out
+wdiff = max((p - q).abs().max().item() for (n, p), (_, q) in zip(gm.named_parameters(), em.named_parameters())
+            if not n.endswith(".0.bias"))
+assert wdiff < 2e-5, wdiff
 dist.destroy_process_group()
 print("RCCL_OK worst relative gradient difference SyncBN vs BatchNorm: %.2e; captured step with collectives: "
       "loss diff %.1e, weight diff %.1e, no host sync in the replay" % (worst, worst_loss, wdiff))
