@@ -75,6 +75,12 @@ def parse():
                          "and evaluates the params of the next `slots`)")
     ap.add_argument("--dets-per-sample", type=int, default=-1,
                     help="ablation: exactly this many detections per sample instead of the synthetic 0..6 legs")
+    ap.add_argument("--graph-collectives", action="store_true",
+                    help="N > 1: also time the box-head step as ONE hipGraph with the RCCL collectives captured inside "
+                         "(validated on a one-rank group in the GPU suite; opt-in so that a first multi-rank run "
+                         "cannot stall the headline line)")
+    ap.add_argument("--no-host-fed", action="store_true",
+                    help="skip the host-fed extra (profile passes: its one-batch launches share the headline kernel's name)")
     ap.add_argument("--no-single", action="store_true",
                     help="skip the one-batch-per-launch and float64 legs (PMC passes: one launch shape per kernel name)")
     ap.add_argument("--no-params", action="store_true",
@@ -432,7 +438,8 @@ def main():
             sys.stderr.write("bench.py: %s failed on rank %d:\n%s\n" % (fn.__name__, rank, traceback.format_exc()))
             return {"error": "%s: %s" % (type(e).__name__, e)}
 
-    box = None if (a.no_extra or a.no_train) else guarded(bench_box_head, dev, world, rank, backend, barrier)
+    box = None if (a.no_extra or a.no_train) else guarded(bench_box_head, dev, world, rank, backend, barrier,
+                                                            a.graph_collectives)
     det_train = None if (a.no_extra or a.no_model or a.no_train) else guarded(bench_detector_train, ops, synth, tab, dev,
                                                                              world, rank, backend, barrier)
 
@@ -532,7 +539,8 @@ def main():
         if det_train is not None:
             result["detector_train"] = det_train
         if not a.no_extra and world == 1:   # per-kernel extras only on the single-GPU line
-            result["host_fed"] = bench_host_fed(ops, sb, tab, dev)
+            if not a.no_host_fed:
+                result["host_fed"] = bench_host_fed(ops, sb, tab, dev)
             result["cutout"] = bench_cutout(ops, synth, tab, dev, variants=not a.no_model)
             result["cutout_dense"] = bench_cutout_dense(ops, synth, dev)
             result["spatial_attention"] = bench_attention(ops, dev)
@@ -540,6 +548,7 @@ def main():
             result["small_kernels"] = bench_small_kernels(ops, synth, tab, dev)
             if not a.no_model:
                 result["dr_spaam_forward"] = bench_dr_spaam(ops, synth, tab, dev)
+                result["prototype_forward"] = guarded(bench_prototype, ops, dev)
             # PMC traffic of the same shapes, read from the committed counter passes (tools/collect_profiles.sh
             # runs this very function under rocprofv3 --pmc): not measured in this run
             for key, pref in (("cutout", ("cutout_area_kernel", "cutout_kernel<1, 7, 1,")),
@@ -556,7 +565,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
+def bench_box_head(dev, world, rank, backend, barrier, graph_collectives=False, steps=30, warm=5):
     """BASELINE configs[3]: one optimisation step of the box-regression head (train_box_regression_1.yaml: PointNet
     on 64-point segments, batch 256 PER RANK, Adam with amsgrad), batch-sharded: forward + backward, ONE flat
     gradient all-reduce over RCCL (dist.GradientAllReduce, 3.8 MB) between backward and the optimiser step,
@@ -624,7 +633,7 @@ def bench_box_head(dev, world, rank, backend, barrier, steps=30, warm=5):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     graphed = None
-    if world == 1 or backend == "nccl":
+    if world == 1 or (backend == "nccl" and graph_collectives):
         # the same step as ONE hipGraph replay (graph_step.GraphedTrainStep): ~150 small kernels, eager pacing is the
         # host's.  With more ranks the SyncBatchNorm collectives and the gradient all-reduce are nodes of the graph
         # (RCCL is stream-ordered and capturable); a host-side backend (the gloo rehearsal) cannot be captured.
@@ -984,6 +993,36 @@ def bench_dr_spaam(ops, synth, tab, dev):
             "ms_per_call": ms, "scans_per_s": B / (ms * 1e-3), "data": "synthetic scans, random-init weights",
             "roofline": {"bound": "mfma", "kernel": "conv3_kernel<4> (float32 MFMA implicit GEMM)", "achieved": ach,
                          "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}}
+
+
+def bench_prototype(ops, dev):
+    """N2: the Prototype flow network (three stride-2 encoders on both scans of a pair, banded correlation, two
+    decoders, point-wise head) in inference, random-init weights of the reference architecture: every unit on
+    pof_conv1d_bn_lrelu after fuse_for_inference(), against the same modules through MIOpen."""
+    import torch
+    from planar_optical_flow_amd.src.depracted.model.prototype import Prototype
+    B, n = 4096, N_PTS
+    torch.manual_seed(7)
+    model = Prototype(in_channel=1, max_displacement=5).to(dev).eval()
+    g = torch.Generator(device=dev).manual_seed(11)
+    s1 = torch.randn((B, n, 1), device=dev, generator=g)
+    s2 = torch.randn((B, n, 1), device=dev, generator=g)
+
+    def step():
+        with torch.no_grad():
+            return model(s1, s2)
+    ms_lib = _time_kernel(torch, step, 3, warm=2)
+    model.fuse_for_inference()
+    ms = _time_kernel(torch, step, 5, warm=2)
+    l0, l1, l2 = (n + 1) // 2, ((n + 1) // 2 + 1) // 2, (((n + 1) // 2 + 1) // 2 + 1) // 2
+    flops = B * 2.0 * (2 * (l0 * 3 * 1 * 64 + l1 * 3 * 64 * 128 + l2 * 3 * 128 * 256)
+                       + l1 * 3 * 139 * 128 + l0 * 3 * 192 * 128 + n * 129 * 2 + 11 * l2 * 768)
+    ach = flops / (ms * 1e-3) / 1e12
+    return {"workload": "Prototype forward, %d scan pairs x %d points (inference, BatchNorm folded)" % (B, n),
+            "ms_per_call": ms, "pairs_per_s": B / (ms * 1e-3), "ms_per_call_library_modules": ms_lib,
+            "data": "synthetic scans, random-init weights",
+            "roofline": {"bound": "mfma", "kernel": "conv1d_kernel<CT, 3, 2 | 3, 1 | 1, 1> (float32 MFMA implicit GEMM)",
+                         "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}}
 
 
 def bench_band_corr(ops, dev):

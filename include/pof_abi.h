@@ -404,6 +404,15 @@ int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, cons
                        int S, int Ci, int Co, int L, int pool, double negative_slope, float *out,
                        pof_stream_t stream);
 
+/* The same layer with kernel_size 1 or 3 (padding kernel_size / 2) and stride 1 or 2 (round 3): the units of the
+ * Prototype flow network -- Conv1d(k = 3, stride 2 | 1) / Conv1d(k = 1) + BatchNorm(eval) + LeakyReLU --
+ * src/depracted/model/prototype.py:6-25, 38-45.  wt [kernel_size][Ci][Co]; out [S][Co][Lc] with
+ * Lc = L (stride 1) or (L + 1) / 2 (stride 2), halved again when pool != 0 (stride 1 only, Lc even).
+ * Supported: (3, 1), (3, 2), (1, 1); anything else returns POF_E_SHAPE. */
+int pof_conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
+                        int S, int Ci, int Co, int L, int kernel_size, int stride, int pool,
+                        double negative_slope, float *out, pof_stream_t stream);
+
 /* ----------------------------------------------------------------------
  * N2 detector heads, inference                  src/depracted/model/dr_spaam.py:104-121
  * pred_cls[s][o] = b_cls[o] + sum_c w_cls[o][c] * mean_l feat[s][c][l]   (o < n_cls <= 6)

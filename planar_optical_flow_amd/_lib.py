@@ -58,6 +58,7 @@ SIGNATURES = {
     "pof_associate_odometry": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p, _p, _p]),
     "pof_rotate_iou": (_i, [_p, _p, _p, _i, _i, _i, _p, _p, _i, _i, _p]),
     "pof_conv3_bn_lrelu": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
+    "pof_conv1d_bn_lrelu": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _d, _p, _p]),
     "pof_bn_lrelu_pool_workspace_bytes": (_sz, [_ll, _i, _i, _i]),
     "pof_bn_lrelu_pool_forward": (_i, [_p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _d, _d, _i, _p, _p, _p, _p, _sz, _p]),
     "pof_bn_lrelu_pool_backward": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _sz, _p]),

@@ -27,7 +27,7 @@ namespace {
 
 constexpr int kCvWaves = 4;
 constexpr int kCvCC = 4;             // input channels per LDS weight chunk
-constexpr int kCvRows = 3 * kCvCC;   // K rows per chunk (tap-major)
+constexpr int kCvRows = 3 * kCvCC;   // K rows per chunk (tap-major), kernel width 3 (the split-K form)
 constexpr long long kCvFillWorkgroups = 256;    // one workgroup = one wave per SIMD on each of the 256 CUs
 using f32x16 = float __attribute__((ext_vector_type(16)));
 
@@ -38,6 +38,7 @@ struct ConvArgs {
     const float *shift;   // [Co]
     float *out;           // [S][Co][Lout]
     int S, Ci, Co, L, pool;
+    int Lc;               // positions the convolution produces per sequence: L (stride 1), (L + 1) / 2 (stride 2)
     float slope;
 };
 
@@ -52,11 +53,11 @@ template <int CT>
 __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&acc)[CT], const float *s_scale,
                                               const float *s_shift, int co0, int seq, int l, int h, bool col_ok)
 {
-    const int Lout = a.pool ? a.L / 2 : a.L;
+    const int Lout = a.pool ? a.Lc / 2 : a.Lc;
     const bool slope01 = a.slope >= 0.0f && a.slope <= 1.0f;                          // uniform
     const long long obase = (long long)seq * a.Co * Lout + (a.pool ? l / 2 : l);      // element offset of (seq, co = 0, l)
     const bool small = (long long)a.S * a.Co * Lout < (1LL << 30);                    // uniform: 32-bit byte offsets
-    const bool writer = col_ok && (!a.pool || (!(l & 1) && l + 1 < a.L));
+    const bool writer = col_ok && (!a.pool || (!(l & 1) && l + 1 < a.Lc));
 #pragma unroll
     for (int t = 0; t < CT; ++t) {
         const bool tile_full = co0 + t * 32 + 31 < a.Co;                               // uniform
@@ -85,13 +86,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
     }
 }
 
-template <int CT>
-__global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
+// KW taps (1 or 3, padding KW / 2), STRIDE 1 or 2 (round 3: the Prototype's stride-2 encoders and the point-wise heads
+// leave the library as well); the DR-SPAAM trunk is <CT, 3, 1>.
+template <int CT, int KW, int STRIDE>
+__global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
 {
+    constexpr int kRows = KW * kCvCC;                  // K rows per chunk (tap-major)
+    constexpr int kPad = KW / 2;
     constexpr int COG = 32 * CT;                       // output channels per workgroup
     constexpr int NT = 64 * kCvWaves;
     constexpr int NP = kCvCC / 2;                      // channel pairs (k-steps) per tap and chunk
-    __shared__ __attribute__((aligned(16))) float s_w[2][kCvRows][COG];   // double-buffered weight chunk
+    __shared__ __attribute__((aligned(16))) float s_w[2][kRows][COG];   // double-buffered weight chunk
     __shared__ __attribute__((aligned(16))) float s_scale[COG], s_shift[COG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -101,28 +106,35 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
         s_scale[threadIdx.x] = a.scale[cs];
         s_shift[threadIdx.x] = a.shift[cs];
     }
-    const long long ncol = (long long)a.S * a.L;
+    const long long ncol = (long long)a.S * a.Lc;
     const long long n_g = ((long long)blockIdx.x * kCvWaves + wave) * 32 + r;   // this lane's column
     const bool col_ok = n_g < ncol;
     const long long nc = col_ok ? n_g : ncol - 1;
-    const int seq = (int)(nc / a.L), l = (int)(nc - (long long)seq * a.L);
-    const bool tap_ok[3] = {col_ok && l > 0, col_ok, col_ok && l < a.L - 1};
+    const int seq = (int)(nc / a.Lc), l = (int)(nc - (long long)seq * a.Lc);    // l: output position
+    bool tap_ok[KW];
+#pragma unroll
+    for (int tap = 0; tap < KW; ++tap) {
+        const int li = l * STRIDE + tap - kPad;                                   // input position of this tap
+        tap_ok[tap] = col_ok && li >= 0 && li < a.L;
+    }
     // 32-bit element offsets of x[seq][h][l + tap - 1] relative to the (uniform) channel row base:
     // border / tail lanes point at a valid neighbour and are zeroed after the load
     // (BYTE offsets: SGPR base + zero-extended 32-bit VGPR offset is the global_load saddr form,
     // which needs no 64-bit address registers per load)
-    const unsigned base_off = (unsigned)((long long)seq * a.Ci * a.L + l);
-    unsigned off_h[3], off_0[3];
+    const unsigned base_off = (unsigned)((long long)seq * a.Ci * a.L + l * STRIDE);
+    unsigned off_h[KW], off_0[KW];
 #pragma unroll
-    for (int tap = 0; tap < 3; ++tap) {
-        off_0[tap] = (base_off + (tap_ok[tap] ? tap - 1 : 0)) * 4u;
+    for (int tap = 0; tap < KW; ++tap) {
+        // a tap outside the sequence points at the lane's own centre element (always inside: l * STRIDE < L) and is
+        // zeroed after the load
+        off_0[tap] = (base_off + (tap_ok[tap] ? tap - kPad : 0)) * 4u;
         off_h[tap] = off_0[tap] + (unsigned)(h * a.L) * 4u;
     }
     const int nchunk = (a.Ci + kCvCC - 1) / kCvCC;
 
     // weight chunk -> registers (16-byte loads along co; uniform chunk base + per-thread byte offsets
     // that do not change from chunk to chunk), registers -> LDS
-    constexpr int WV = (kCvRows * COG / 4 + NT - 1) / NT;       // float4 groups per thread and chunk
+    constexpr int WV = (kRows * COG / 4 + NT - 1) / NT;       // float4 groups per thread and chunk
     using F4V = float __attribute__((ext_vector_type(4)));
     F4V wreg[WV];
     unsigned woff[WV];      // ((tap * Ci + cl) * Co + c) * 4 bytes
@@ -133,7 +145,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
         const int e4 = threadIdx.x + q * NT;
         const int row = e4 / (COG / 4), c = (e4 - row * (COG / 4)) * 4;
         const int tap = row / kCvCC, cl = row - tap * kCvCC;
-        const bool in = e4 < kCvRows * COG / 4 && co0 + c < a.Co;
+        const bool in = e4 < kRows * COG / 4 && co0 + c < a.Co;
         woff[q] = in ? (unsigned)(((long long)tap * a.Ci + cl) * a.Co + c) * 4u : 0u;
         wcl[q] = in ? cl : kCvCC;
     }
@@ -160,15 +172,15 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
 #pragma unroll
         for (int q = 0; q < WV; ++q) {
             const int e4 = threadIdx.x + q * NT;
-            if (e4 < kCvRows * COG / 4) reinterpret_cast<F4V *>(&s_w[buf][0][0])[e4] = wreg[q];
+            if (e4 < kRows * COG / 4) reinterpret_cast<F4V *>(&s_w[buf][0][0])[e4] = wreg[q];
         }
     };
     // activation operands of one chunk: 3 taps x NP channel pairs, uniform row base + lane offset
-    float xb[2][3][NP];
+    float xb[2][KW][NP];
     auto load_x = [&](int set, int ci0) {
         const int cc = min(kCvCC, a.Ci - ci0);
 #pragma unroll
-        for (int tap = 0; tap < 3; ++tap)
+        for (int tap = 0; tap < KW; ++tap)
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
                 const int c2 = min(2 * p, cc - 1);                               // uniform
@@ -200,9 +212,9 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv3_kernel(ConvArgs a)
 #pragma unroll
         for (int t = 0; t < CT; ++t) a_cur[t] = s_w[SET][h][t * 32 + r];
 #pragma unroll
-        for (int ks = 0; ks < 3 * NP; ++ks) {
+        for (int ks = 0; ks < KW * NP; ++ks) {
             const int tap = ks / NP, p = ks - tap * NP;
-            if (ks + 1 < 3 * NP) {
+            if (ks + 1 < KW * NP) {
                 const int tn = (ks + 1) / NP, pn = (ks + 1) - tn * NP;
 #pragma unroll
                 for (int t = 0; t < CT; ++t) a_nxt[t] = s_w[SET][tn * kCvCC + 2 * pn + h][t * 32 + r];
@@ -378,28 +390,38 @@ __global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_splitk_kernel(ConvArgs
 
 }  // namespace
 
-extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
-                                  int S, int Ci, int Co, int L, int pool, double negative_slope, float *out,
-                                  pof_stream_t stream)
+namespace {
+
+template <int KW, int STRIDE>
+void launch_conv1d(const ConvArgs &a, dim3 grid, int ct, hipStream_t s)
 {
-    POF_CLEAR_STALE_ERROR();
+    if (ct == 1) conv1d_kernel<1, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
+    else if (ct == 2) conv1d_kernel<2, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
+    else conv1d_kernel<4, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
+}
+
+int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift, int S, int Ci, int Co,
+                    int L, int kernel, int stride, int pool, double negative_slope, float *out, pof_stream_t stream)
+{
     if (!x || !wt || !scale || !shift || !out) return POF_E_BADARG;
     if (S < 0 || Ci < 1 || Co < 1 || L < 1) return POF_E_BADARG;
-    if (pool && (L < 2 || (L & 1))) return POF_E_SHAPE;   // pooled pairs sit on adjacent lanes: even L
+    if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 1 && stride == 1))) return POF_E_SHAPE;
+    const int Lc = stride == 1 ? L : (L + 1) / 2;         // (L + 2 pad - kernel) / stride + 1 with pad = kernel / 2
+    if (pool && (stride != 1 || Lc < 2 || (Lc & 1))) return POF_E_SHAPE;   // pooled pairs sit on adjacent lanes: even L
     if (S == 0) return POF_OK;
     // 32-bit byte offsets per lane inside one launch: sequences go in chunks of < 2^30 input elements
     const long long per_seq = (long long)Ci * L;
     if (per_seq >= (1LL << 30)) return POF_E_SHAPE;
     const int s_max = (int)std::min<long long>(S, ((1LL << 30) - 1) / per_seq);
-    const int Lout = pool ? L / 2 : L;
+    const int Lout = pool ? Lc / 2 : Lc;
     hipStream_t s = pof_stream(stream);
     for (int s0 = 0; s0 < S; s0 += s_max) {
         ConvArgs a;
         a.S = std::min(s_max, S - s0);
         a.x = x + (long long)s0 * per_seq; a.wt = wt; a.scale = scale; a.shift = shift;
         a.out = out + (long long)s0 * Co * Lout;
-        a.Ci = Ci; a.Co = Co; a.L = L; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
-        const long long ncol = (long long)a.S * L;
+        a.Ci = Ci; a.Co = Co; a.L = L; a.Lc = Lc; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
+        const long long ncol = (long long)a.S * Lc;
         const long long tiles = (ncol + 31) / 32;
         const long long gx = (tiles + kCvWaves - 1) / kCvWaves;
         if (gx > 0x7fffffffLL) return POF_E_SHAPE;
@@ -408,18 +430,19 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
         // (streaming inference: a few dozen column tiles) leaves SIMDs idle and is bound by one wave's serial
         // K loop, so it takes narrower channel groups -- more and proportionally shorter workgroups, same
         // summation order, bit-identical results
-        int ct = Co <= 64 ? 2 : 4;
+        int ct = Co <= 32 ? 1 : (Co <= 64 ? 2 : 4);
         while (ct > 1 && gx * ((Co + 32 * ct - 1) / (32 * ct)) < kCvFillWorkgroups) ct >>= 1;
         // fewer than two resident rounds of 128-channel workgroups (4 per CU x 256 CUs): the last, partly filled round
         // costs a whole round -- 64-channel workgroups quantise finer (measured at S = 3600, one scan of a training
-        // batch: 256 -> 256 L = 14 0.234 -> 0.218 ms, 512 -> 256 L = 14 0.425 -> 0.390, 256 -> 128 L = 28 0.214 -> 0.195;
-        // tools/exp_conv_ct.py), at equal summation order
+        // batch: 256 -> 256 L = 14 0.234 -> 0.218 ms, 512 -> 256 L = 14 0.425 -> 0.390, 256 -> 128 L = 28 0.214 -> 0.195),
+        // at equal summation order
         if (ct == 4 && gx * ((Co + 127) / 128) < 8 * kCvFillWorkgroups) ct = 2;
         { static const int force = [] { const char *e = getenv("POF_CONV_CT"); return e ? atoi(e) : 0; }();
           if (force == 1 || force == 2 || force == 4) ct = (Co <= 32 && force > 1) ? 1 : (Co <= 64 && force > 2) ? 2 : force; }
         const long long wgs = gx * ((Co + 32 * ct - 1) / (32 * ct));
         const int nchunk = (Ci + kCvCC - 1) / kCvCC;
-        if (wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves && tiles <= 0x7fffffffLL) {
+        if (kernel == 3 && stride == 1 && wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves &&
+            tiles <= 0x7fffffffLL) {
             // still a launch that leaves most SIMDs with at most one wave, and a K loop long enough to pay for
             // the reduction (Ci >= 128; measured at one scan per call: 512->256 L=7 92 -> 58 us, 256->128 L=7
             // 43 -> 19 us, 256->256 L=14 52 -> 45 us; the widening layers Co = 2 Ci and Ci = 64 lose 10-50 %
@@ -430,11 +453,29 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
             else conv3_splitk_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
         } else {
             const dim3 grid((unsigned)gx, (Co + 32 * ct - 1) / (32 * ct));
-            if (ct == 1) conv3_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
-            else if (ct == 2) conv3_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
-            else conv3_kernel<4><<<grid, 64 * kCvWaves, 0, s>>>(a);
+            if (kernel == 1) launch_conv1d<1, 1>(a, grid, ct, s);
+            else if (stride == 2) launch_conv1d<3, 2>(a, grid, ct, s);
+            else launch_conv1d<3, 1>(a, grid, ct, s);
         }
         POF_CHECK_LAUNCH();
     }
     return POF_OK;
+}
+
+}  // namespace
+
+extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
+                                  int S, int Ci, int Co, int L, int pool, double negative_slope, float *out,
+                                  pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return conv1d_bn_lrelu(x, wt, scale, shift, S, Ci, Co, L, 3, 1, pool, negative_slope, out, stream);
+}
+
+extern "C" int pof_conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,
+                                   int S, int Ci, int Co, int L, int kernel_size, int stride, int pool,
+                                   double negative_slope, float *out, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    return conv1d_bn_lrelu(x, wt, scale, shift, S, Ci, Co, L, kernel_size, stride, pool, negative_slope, out, stream);
 }

@@ -449,6 +449,33 @@ def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None
     return out
 
 
+def conv1d_bn_lrelu(x, wt, scale, shift, stride=1, pool=False, negative_slope=0.1, out=None):
+    """Conv1d(kernel 1 | 3, padding kernel // 2, stride 1 | 2) + folded BatchNorm + LeakyReLU [+ max_pool1d(2)] on the
+    float32-MFMA implicit-GEMM kernel: x [S,Ci,L] f32, wt [kernel,Ci,Co] f32 (conv weight transposed), scale / shift
+    [Co] -> [S, Co, Lc] with Lc = L (stride 1) | (L + 1) // 2 (stride 2), halved when pooled."""
+    x = _dev(x, torch.float32, "x")
+    wt = _dev(wt, torch.float32, "wt")
+    scale = _dev(scale, torch.float32, "scale")
+    shift = _dev(shift, torch.float32, "shift")
+    S, Ci, L = x.shape
+    if wt.dim() != 3 or wt.shape[0] not in (1, 3) or wt.shape[1] != Ci:
+        raise ValueError("wt must be [1 | 3, Ci, Co]")
+    K, Co = int(wt.shape[0]), int(wt.shape[2])
+    if scale.numel() != Co or shift.numel() != Co:
+        raise ValueError("scale / shift must have Co entries")
+    Lc = L if stride == 1 else (L + 1) // 2
+    Lout = Lc // 2 if pool else Lc
+    if out is None:
+        out = torch.empty((S, Co, Lout), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, torch.float32, "out")
+    if S > 0:
+        with torch.cuda.device(x.device):
+            _lib.call("pof_conv1d_bn_lrelu", _ptr(x), _ptr(wt), _ptr(scale), _ptr(shift), S, Ci, Co, L, K, int(stride),
+                      int(bool(pool)), float(negative_slope), _ptr(out), _stream())
+    return out
+
+
 def drow_heads(feat, w_cls, b_cls, w_reg, b_reg):
     """N2 heads (inference): feat [S,C,L] f32, w_cls [n_cls,C], w_reg [2,C] -> (pred_cls [S,n_cls], pred_reg [S,2]):
     mean over positions + both 1x1 convolutions in one launch."""

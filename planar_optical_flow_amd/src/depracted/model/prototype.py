@@ -1,7 +1,11 @@
 """HIP-backed pieces of the reference's ``src/depracted/model/prototype.py``:
 the banded patch correlation ``Prototype._fusion`` (:118-156) and the per-sample
-EPE ``flow_loss`` (:27-32).  The 1-D conv encoder/decoder around them is plain
-``torch.nn`` in the reference and stays on MIOpen.
+EPE ``flow_loss`` (:27-32).  The 1-D conv encoder / decoder around them is plain
+``torch.nn`` in the reference; here the modules keep the reference's parameters and
+state-dict keys, training runs them through torch, and inference -- after
+``fuse_for_inference()`` -- runs every unit (stride-2 and stride-1 k = 3 convolutions, the
+point-wise head, BatchNorm folded, LeakyReLU) on the float32-MFMA kernel ``pof_conv1d_bn_lrelu``
+(round 3), both scans of a pair in one launch per layer.
 
 The correlation is an autograd Function (HIP forward and backward), so it composes
 with the torch encoder/decoder for end-to-end training.
@@ -69,10 +73,55 @@ class Prototype(nn.Module):
     def _upsample(x, size):
         return F.interpolate(x, size=size, mode="nearest")
 
+    _UNITS = ("encoder_0", "encoder_1", "encoder_2", "decoder_1", "decoder_0", "flow_reg")
+
+    def fuse_for_inference(self, enable=True):
+        """Fold every unit's Conv1d bias + BatchNorm (running statistics) into (transposed weight [k, Ci, Co], scale,
+        shift) for ``pof_conv1d_bn_lrelu``.  Call after loading a checkpoint and after ``.cuda()``; eval-mode forwards on
+        the device then leave MIOpen entirely.  ``train()`` drops the folded copy."""
+        self._fused = None
+        if enable:
+            fused = {}
+            with torch.no_grad():
+                for name in self._UNITS:
+                    conv, bn, act = getattr(self, name)
+                    scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+                    shift = bn.bias + (conv.bias - bn.running_mean) * scale
+                    fused[name] = (conv.weight.permute(2, 1, 0).contiguous().float(), scale.float().contiguous(),
+                                   shift.float().contiguous(), int(conv.stride[0]), float(act.negative_slope))
+            self._fused = fused
+        return self
+
+    def train(self, mode=True):
+        if mode:
+            self._fused = None
+        return super().train(mode)
+
+    def _unit_hip(self, name, x):
+        wt, scale, shift, stride, slope = self._fused[name]
+        return ops.conv1d_bn_lrelu(x.contiguous(), wt, scale, shift, stride=stride, negative_slope=slope)
+
+    def _forward_fused(self, scan1, scan2):
+        B = scan1.shape[0]
+        s1 = scan1.permute(0, 2, 1).contiguous().float()
+        both = torch.cat((s1, scan2.permute(0, 2, 1).contiguous().float()), dim=0)     # [2B, C, n]: one launch per layer
+        skips, f = [], both
+        for name in ("encoder_0", "encoder_1", "encoder_2"):
+            f = self._unit_hip(name, f)
+            skips.append(f[:B])
+        out = self._fusion(f[:B], f[B:], max_displacement=self.max_displacement)
+        for name, skip in (("decoder_1", skips[1]), ("decoder_0", skips[0])):
+            out = self._unit_hip(name, torch.cat((skip, self._upsample(out, size=skip.shape[-1])), dim=1))
+        out = self._unit_hip("flow_reg", torch.cat((s1, self._upsample(out, size=s1.shape[-1])), dim=1))
+        return out.permute(0, 2, 1)
+
     def forward(self, scan1, scan2=None):
         """scan1, scan2 [B, n_pts, n_channel] -> per-point flow [B, n_pts, 2]."""
         if scan2 is None:
             scan2 = scan1
+        if getattr(self, "_fused", None) is not None and not self.training and scan1.is_cuda \
+                and not torch.is_grad_enabled():
+            return self._forward_fused(scan1, scan2)
         s1, s2 = scan1.permute(0, 2, 1), scan2.permute(0, 2, 1)
         skips, f1, f2 = [], s1, s2
         for enc in (self.encoder_0, self.encoder_1, self.encoder_2):

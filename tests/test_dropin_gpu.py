@@ -464,8 +464,15 @@ def test_prototype_forward_equals_reference(golden):
     s1, s2 = torch.from_numpy(g["s1"]).cuda(), torch.from_numpy(g["s2"]).cuda()
     m.eval()
     with torch.no_grad():
-        np.testing.assert_allclose(m(s1, s2).cpu().numpy(), g["eval_out"], rtol=1e-3, atol=2e-4)
+        plain = m(s1, s2)
+        np.testing.assert_allclose(plain.cpu().numpy(), g["eval_out"], rtol=1e-3, atol=2e-4)
+        # the same forward with every unit on the HIP conv kernel (stride-2 / stride-1 k = 3, k = 1; BatchNorm folded)
+        m.fuse_for_inference()
+        fused = m(s1, s2)
+        np.testing.assert_allclose(fused.cpu().numpy(), g["eval_out"], rtol=1e-3, atol=2e-4)
+        np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=2e-5)
     m.train()
+    assert m._fused is None
     out = m(s1, s2)
     np.testing.assert_allclose(out.detach().cpu().numpy(), g["train_out"], rtol=2e-3, atol=1e-3)
     loss, err = m.loss_fn(out, torch.zeros_like(out))

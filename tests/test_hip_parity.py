@@ -831,6 +831,36 @@ def test_conv3_bn_lrelu_layer(ops, S, Ci, Co, L, pool):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("S,Ci,Co,L,K,stride", [(6, 1, 64, 450, 3, 2), (5, 64, 128, 225, 3, 2), (4, 128, 256, 113, 3, 2),
+                                                 (3, 139, 128, 113, 3, 1), (2, 192, 128, 225, 3, 1), (3, 129, 2, 450, 1, 1),
+                                                 (7, 3, 64, 64, 1, 1), (2, 5, 33, 9, 3, 2), (1, 2, 3, 1, 3, 2), (2, 7, 70, 2, 1, 1)])
+def test_conv1d_bn_lrelu_kernel_and_stride(ops, S, Ci, Co, L, K, stride):
+    """pof_conv1d_bn_lrelu -- the Prototype's units: Conv1d(k = 3 | 1, padding k // 2, stride 2 | 1) + folded BatchNorm +
+    LeakyReLU(0.01) -- against torch: exact on integer data (indexing, borders of odd lengths, channel / column tails),
+    1e-4 on random float data."""
+    gen = torch.Generator(device="cpu").manual_seed(S * 1000 + Ci + 7 * K + stride)
+    def reference(x, w, scale, shift, slope):
+        y = torch.nn.functional.conv1d(x, w, None, stride=stride, padding=K // 2) * scale[None, :, None] + shift[None, :, None]
+        return torch.nn.functional.leaky_relu(y, slope)
+    x = torch.randint(-3, 4, (S, Ci, L), generator=gen).float().to(DEV)
+    w = torch.randint(-2, 3, (Co, Ci, K), generator=gen).float().to(DEV)
+    scale = torch.full((Co,), 0.5, device=DEV)
+    shift = torch.randint(-4, 5, (Co,), generator=gen).float().to(DEV)
+    got = ops.conv1d_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, stride=stride, negative_slope=0.125)
+    want = reference(x.double(), w.double(), scale.double(), shift.double(), 0.125).float()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    assert torch.equal(got, want), (got - want).abs().max().item()
+    x = torch.randn((S, Ci, L), generator=gen).to(DEV)
+    w = (torch.randn((Co, Ci, K), generator=gen) / (K * Ci) ** 0.5).to(DEV)
+    scale = (torch.rand((Co,), generator=gen) + 0.5).to(DEV)
+    shift = torch.randn((Co,), generator=gen).to(DEV)
+    got = ops.conv1d_bn_lrelu(x, w.permute(2, 1, 0).contiguous(), scale, shift, stride=stride, negative_slope=0.01)
+    want = reference(x.double(), w.double(), scale.double(), shift.double(), 0.01).float()
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    with pytest.raises(Exception):
+        ops.conv1d_bn_lrelu(x, torch.zeros((1, Ci, Co), device=DEV), scale, shift, stride=2)     # k = 1 with stride 2
+
+
 def test_conv3_bn_lrelu_sequence_chunking(ops):
     """More than 2^30 input elements: the entry point splits the sequences over several launches
     (32-bit lane offsets inside one launch); sequences either side of the split match torch."""

@@ -9,15 +9,15 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 # counters in their own runs (no tracing), one counter per pass
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 40 --warmup 8 --repeats 1 --no-single --no-cpu-baseline --no-model --no-train > /dev/null 2> $OUT/pmc_fetch.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 bench.py --steps 40 --warmup 8 --repeats 1 --no-single --no-host-fed --no-cpu-baseline --no-model --no-train > /dev/null 2> $OUT/pmc_fetch.err
 echo "fetch pass done" >> $OUT/progress.txt
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 40 --warmup 8 --repeats 1 --no-single --no-cpu-baseline --no-model --no-train > /dev/null 2> $OUT/pmc_write.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 bench.py --steps 40 --warmup 8 --repeats 1 --no-single --no-host-fed --no-cpu-baseline --no-model --no-train > /dev/null 2> $OUT/pmc_write.err
 echo "pmc passes done" >> $OUT/progress.txt
 python3 tools/parse_pmc.py $OUT/pmc_fetch $OUT/pmc_write > $OUT/pmc_traffic.json
 cp $OUT/pmc_traffic.json profiles/${TAG}_pmc_traffic.json      # bench.py reads the newest profiles/*_pmc_traffic.json
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench exit $?"; echo "bench done" >> $OUT/progress.txt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_trace_$TAG -- python3 bench.py --steps 24 --warmup 8 --no-single --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_trace_$TAG -- python3 bench.py --steps 24 --warmup 8 --no-single --no-host-fed --no-cpu-baseline > $OUT/bench_traced.json 2> $OUT/trace.err
 cp $(find /tmp/pof_trace_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_trace1_$TAG -- python3 bench.py --steps 24 --warmup 8 --slots 1 --no-cpu-baseline --no-extra > $OUT/bench_traced_single_slot.json 2> $OUT/trace1.err
 cp $(find /tmp/pof_trace1_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_single_slot.csv

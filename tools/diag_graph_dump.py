@@ -30,14 +30,18 @@ det(scan)                                   # steady-state step, eager (lazy ini
 if mode == "dropped":
     det._cut_ws = None                      # ops.cutout then allocates (and drops) its word inside the capture
 torch.cuda.synchronize()
-g = torch.cuda.CUDAGraph()
-g.enable_debug_mode()
+# torch's debug_dump() writes nothing on ROCm: keep the captured graph and call hipGraphDebugDotPrint on its handle
+import ctypes
+g = torch.cuda.CUDAGraph(keep_graph=True)
 with torch.cuda.graph(g):
     cls, reg, tmpl, fused = det._step(False)
     det.template.copy_(tmpl)
 path = os.path.join(REPO, "gpurun_out", "r3_stream_graph_%s.dot" % mode)
 os.makedirs(os.path.dirname(path), exist_ok=True)
-g.debug_dump(path)
+hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+hip.hipGraphDebugDotPrint.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_uint]
+rc = hip.hipGraphDebugDotPrint(ctypes.c_void_p(g.raw_cuda_graph()), path.encode(), 1)     # 1 = verbose
+print("hipGraphDebugDotPrint rc", rc)
 txt = open(path).read()
 nodes = dict(re.findall(r'"?(graph_\d+_node_\d+|\d+)"?\s*\[([^\]]*)\]', txt))
 edges = re.findall(r'"?(graph_\d+_node_\d+|\d+)"?\s*->\s*"?(graph_\d+_node_\d+|\d+)"?', txt)
