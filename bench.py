@@ -495,6 +495,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_per_step": (traffic / S if traffic else None),
                          "traffic_source": traffic_src,
                          "clock": "wall (the interval of ms_per_step)",
                          "bytes_per_step": bytes_per_scan * B,

@@ -470,7 +470,7 @@ def test_prototype_forward_equals_reference(golden):
         m.fuse_for_inference()
         fused = m(s1, s2)
         np.testing.assert_allclose(fused.cpu().numpy(), g["eval_out"], rtol=1e-3, atol=2e-4)
-        np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(fused.cpu().numpy(), plain.cpu().numpy(), rtol=1e-4, atol=2e-4)   # outputs of magnitude 20-60
     m.train()
     assert m._fused is None
     out = m(s1, s2)
