@@ -664,7 +664,26 @@ def bench_box_head(dev, world, rank, backend, barrier, graph_collectives=False, 
             t = torch.tensor([gdt], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             gdt = float(t.item())
+        lib_ms = None
+        if world == 1:
+            torch.manual_seed(4)
+            lmodel = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.3}).to(dev)
+            lmodel.backbone.hip_train = False
+            lmodel.train()
+            loptim = Optim(lmodel, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
+            lstep = GraphedTrainStep(lmodel, loptim.make_capturable(), {"input": x, "target": y})
+            for _ in range(warm):
+                loptim.set_lr(0)
+                lstep(batch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10 * steps):
+                loptim.set_lr(0)
+                lstep(batch)
+            torch.cuda.synchronize()
+            lib_ms = (time.perf_counter() - t0) / (10 * steps) * 1e3
         graphed = {"ms_per_step": gdt * 1e3, "samples_per_s": world * per / gdt,
+                   "ms_per_step_library_modules": lib_ms,
                    "note": "zero_grad + forward + backward%s + Adam captured once, replayed per batch (inputs copied "
                            "into static buffers, learning rate a device scalar)"
                            % (" + SyncBatchNorm collectives + gradient all-reduce (RCCL nodes of the graph)" if world > 1 else "")}
@@ -1019,8 +1038,28 @@ def bench_prototype(ops, dev):
     flops = B * 2.0 * (2 * (l0 * 3 * 1 * 64 + l1 * 3 * 64 * 128 + l2 * 3 * 128 * 256)
                        + l1 * 3 * 139 * 128 + l0 * 3 * 192 * 128 + n * 129 * 2 + 11 * l2 * 768)
     ach = flops / (ms * 1e-3) / 1e12
+    # training: forward + backward of the EPE loss at 256 pairs, units as ConvUnitTrain nodes on the HIP kernels
+    # against the same modules through the library
+    from planar_optical_flow_amd.src.depracted.model.prototype import flow_loss
+    tmodel = Prototype(in_channel=1, max_displacement=5).to(dev).train()
+    tb = 256
+    tgt = torch.randn((tb, n, 2), device=dev, generator=g) * 0.2
+
+    def train_step():
+        tmodel.zero_grad(set_to_none=True)
+        loss, _ = flow_loss(tmodel(s1[:tb], s2[:tb]), tgt)
+        loss.backward()
+        return loss
+    train_ms = {}
+    for tag, hip in (("hip_units", True), ("library_modules", False)):
+        tmodel.hip_train = hip
+        train_ms[tag] = _time_kernel(torch, train_step, 5, warm=3)
     return {"workload": "Prototype forward, %d scan pairs x %d points (inference, BatchNorm folded)" % (B, n),
             "ms_per_call": ms, "pairs_per_s": B / (ms * 1e-3), "ms_per_call_library_modules": ms_lib,
+            "train_forward_backward": {"pairs": tb, "ms_hip_units": train_ms["hip_units"],
+                                       "ms_library_modules": train_ms["library_modules"],
+                                       "note": "EPE loss, batch statistics; convolution forward / data / weight gradients "
+                                               "and the BatchNorm tail on the HIP kernels vs MIOpen + ATen"},
             "data": "synthetic scans, random-init weights",
             "roofline": {"bound": "mfma", "kernel": "conv1d_kernel<CT, 3, 2 | 3, 1 | 1, 1> (float32 MFMA implicit GEMM)",
                          "achieved": ach, "peak": 157.3, "unit": "TFLOP/s", "frac": ach / 157.3, "traffic": None}}

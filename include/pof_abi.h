@@ -468,6 +468,22 @@ int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int
 size_t pof_conv3_wgrad_workspace_bytes(int S, int Ci, int Co, int L);
 int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, float *dw,
                     void *workspace, size_t workspace_bytes, pof_stream_t stream);
+/* The same pass for kernel_size 1 | 3 (1: the point-wise convolutions of the box-regression PointNet,
+ * src/model/box_regression.py:8-17, and of the Prototype head, src/depracted/model/prototype.py:52-58):
+ * dw [Co][Ci][kernel_size]; kernel_size 3 is pof_conv3_wgrad. */
+size_t pof_conv1d_wgrad_workspace_bytes(int S, int Ci, int Co, int L, int kernel_size);
+int pof_conv1d_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, int kernel_size, float *dw,
+                     void *workspace, size_t workspace_bytes, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
+ * configs[3] box-regression head, dense layers    src/model/box_regression.py:26-45 (_fc), :139-141
+ * out[b][n] = sum_k x[b][k] * w[n][k] + bias[n] (torch.nn.Linear's forward; x [B][K], w [N][K],
+ * bias [N] or NULL, out [B][N], float32, K a multiple of 4, x and w 16-byte aligned).  For the
+ * head's batch (a few hundred rows): one workgroup per 32 x 32 output tile, K split over its
+ * four waves, float32 MFMA, deterministic.  The backward GEMMs stay with the BLAS library.
+ * ---------------------------------------------------------------------- */
+int pof_linear_bias(const float *x, const float *w, const float *bias, int B, int K, int N, float *out,
+                    pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105

@@ -64,6 +64,9 @@ SIGNATURES = {
     "pof_bn_lrelu_pool_backward": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_conv3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pof_conv3_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "pof_linear_bias": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
+    "pof_conv1d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "pof_conv1d_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "pof_drow_heads": (_i, [_p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p]),
     "pof_segment_inputs": (_i, [_p, _i, _i, _p, _p, _i, _d, _i, _i, C.c_uint32, _p, _p, _p, _p]),
     "pof_segment_resample": (_i, [_p, _i, _p, _i, _i, _p, _p, _d, _i, C.c_uint32, _p, _p, _p]),

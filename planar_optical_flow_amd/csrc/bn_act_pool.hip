@@ -85,6 +85,8 @@ __device__ __forceinline__ void st2(float *p, float a, float b)
     __builtin_nontemporal_store(F2{a, b}, reinterpret_cast<F2 *>(p));
 }
 
+template <int POOL> constexpr int kSampleUnroll = POOL == 2 ? 1 : 4;
+
 struct Lane {
     int p0;          // first plane position of the lane
     int grp;         // statistics group of the workgroup's samples
@@ -203,7 +205,9 @@ __global__ __launch_bounds__(kBnThreads) void bn_finalize_kernel(const double2 *
 
 __device__ __forceinline__ float lrelu(float u, float slope) { return u > 0.0f ? u : u * slope; }
 
-template <bool POOL>
+// POOL: 0 none, 1 max over pairs (max_pool1d(2)), 2 max over the whole row (the PointNet's max over points,
+// src/model/box_regression.py:37-38; L a power of two >= 4, so a row is L / 4 neighbouring lanes of one wave)
+template <int POOL>
 __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__restrict__ y, BnGeo g,
                                                               const float *__restrict__ scale,
                                                               const float *__restrict__ shift, float slope,
@@ -218,14 +222,22 @@ __global__ __launch_bounds__(kBnThreads) void bn_apply_kernel(const float *__res
         sc[i] = scale[c]; sh[i] = shift[c];
     }
     const float *src = y + l.s0 * g.P + l.p0;
-    const int po = POOL ? g.P / 2 : g.P;
-    float *dst = out + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
-#pragma unroll 4
+    const int po = POOL == 2 ? g.C : POOL == 1 ? g.P / 2 : g.P;
+    float *dst = out + l.s0 * po + (POOL == 2 ? l.p0 / g.L : POOL == 1 ? l.p0 / 2 : l.p0);
+    const int lpr = g.L >> 2;       // lanes of a row (POOL == 2)
+    const bool row_head = (threadIdx.x & (lpr - 1)) == 0;
+#pragma unroll kSampleUnroll<POOL>     // (a loop with cross-lane operations is not unrolled with a remainder)
     for (long long s = l.s0; s < l.s1; ++s, src += g.P, dst += po) {
         const float4 v = ld4(src);
         const float z0 = lrelu(fmaf(v.x, sc[0], sh[0]), slope), z1 = lrelu(fmaf(v.y, sc[1], sh[1]), slope);
         const float z2 = lrelu(fmaf(v.z, sc[2], sh[2]), slope), z3 = lrelu(fmaf(v.w, sc[3], sh[3]), slope);
-        if (POOL) st2(dst, z0 >= z1 ? z0 : z1, z2 >= z3 ? z2 : z3);
+        if (POOL == 2) {
+            float m = fmaxf(fmaxf(z0, z1), fmaxf(z2, z3));
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+                if (o < lpr) m = fmaxf(m, __shfl_xor(m, o, 64));
+            if (row_head) *dst = m;
+        } else if (POOL == 1) st2(dst, z0 >= z1 ? z0 : z1, z2 >= z3 ? z2 : z3);
         else st4(dst, z0, z1, z2, z3);
     }
 }
@@ -250,8 +262,8 @@ __device__ __forceinline__ BwdConst bwd_const(const BnGeo &g, int grp, int p0, c
 }
 
 // gradient with respect to the BatchNorm output u, and xhat, for the lane's four positions of one sample
-template <bool POOL>
-__device__ __forceinline__ void grad_u(const float *src, const float *gsrc, const BwdConst &k, float slope,
+template <int POOL>
+__device__ __forceinline__ void grad_u(const float *src, const float *gsrc, const BwdConst &k, float slope, int L,
                                        float (&du)[4], float (&xh)[4])
 {
     const float4 v4 = ld4(src);
@@ -262,7 +274,28 @@ __device__ __forceinline__ void grad_u(const float *src, const float *gsrc, cons
         u[i] = fmaf(v[i], k.sc[i], k.sh[i]);
         xh[i] = (v[i] - k.mu[i]) * k.is[i];
     }
-    if (POOL) {
+    if (POOL == 2) {
+        // the row's FIRST maximum takes the gradient: (value, position) reduced over the row's lanes
+        float z[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = lrelu(u[i], slope);
+        const int lpr = L >> 2, pos0 = 4 * (threadIdx.x & (lpr - 1));
+        float bv = z[0];
+        int bi = pos0;
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (z[i] > bv) { bv = z[i]; bi = pos0 + i; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            if (o >= lpr) continue;
+            const float ov = __shfl_xor(bv, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        const float d = *gsrc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gz[i] = pos0 + i == bi ? d : 0.0f;
+    } else if (POOL == 1) {
         // the pair's winner takes the gradient; max_pool1d keeps the FIRST maximum on a tie
         const float2 d = ld2(gsrc);
         const bool f0 = lrelu(u[0], slope) >= lrelu(u[1], slope), f1 = lrelu(u[2], slope) >= lrelu(u[3], slope);
@@ -276,7 +309,7 @@ __device__ __forceinline__ void grad_u(const float *src, const float *gsrc, cons
     for (int i = 0; i < 4; ++i) du[i] = u[i] > 0.0f ? gz[i] : gz[i] * slope;
 }
 
-template <bool POOL>
+template <int POOL>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *__restrict__ y,
                                                                    const float *__restrict__ dz, BnGeo g,
                                                                    const float *__restrict__ gamma,
@@ -290,13 +323,13 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_reduce_kernel(const float *
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (l.active) {
         const BwdConst k = bwd_const(g, l.grp, l.p0, gamma, beta, mean, invstd);
-        const int po = POOL ? g.P / 2 : g.P;
+        const int po = POOL == 2 ? g.C : POOL == 1 ? g.P / 2 : g.P;
         const float *src = y + l.s0 * g.P + l.p0;
-        const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
-#pragma unroll 4
+        const float *gsrc = dz + l.s0 * po + (POOL == 2 ? l.p0 / g.L : POOL == 1 ? l.p0 / 2 : l.p0);
+#pragma unroll kSampleUnroll<POOL>     // (a loop with cross-lane operations is not unrolled with a remainder)
         for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po) {
             float du[4], xh[4];
-            grad_u<POOL>(src, gsrc, k, slope, du, xh);
+            grad_u<POOL>(src, gsrc, k, slope, g.L, du, xh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) { a[i] += (double)du[i]; b[i] = fma((double)du[i], (double)xh[i], b[i]); }
         }
@@ -332,7 +365,7 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_final_kernel(const double2 
 
 // DSUM: also the per-channel sum of dy (= the gradient of a bias added in front of the BatchNorm, i.e. the
 // convolution's bias; zero in exact arithmetic, the framework reduces dy for it in a pass of its own)
-template <bool POOL, bool DSUM>
+template <int POOL, bool DSUM>
 __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *__restrict__ y,
                                                                   const float *__restrict__ dz, BnGeo g,
                                                                   const float *__restrict__ gamma,
@@ -355,15 +388,15 @@ __global__ __launch_bounds__(kBnThreads) void bn_bwd_dgrad_kernel(const float *_
             const int c = l.grp * g.C + (l.p0 + i) / g.L;
             m1[i] = k1[c]; m2[i] = k2[c];
         }
-        const int po = POOL ? g.P / 2 : g.P;
+        const int po = POOL == 2 ? g.C : POOL == 1 ? g.P / 2 : g.P;
         const float *src = y + l.s0 * g.P + l.p0;
-        const float *gsrc = dz + l.s0 * po + (POOL ? l.p0 / 2 : l.p0);
+        const float *gsrc = dz + l.s0 * po + (POOL == 2 ? l.p0 / g.L : POOL == 1 ? l.p0 / 2 : l.p0);
         float *dst = dy + l.s0 * g.P + l.p0;
         float part[4] = {0, 0, 0, 0};            // at most kStreamK terms each
-#pragma unroll 4
+#pragma unroll kSampleUnroll<POOL>     // (a loop with cross-lane operations is not unrolled with a remainder)
         for (long long s = l.s0; s < l.s1; ++s, src += g.P, gsrc += po, dst += g.P) {
             float du[4], xh[4], r[4];
-            grad_u<POOL>(src, gsrc, k, slope, du, xh);
+            grad_u<POOL>(src, gsrc, k, slope, g.L, du, xh);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 r[i] = k.sc[i] * ((du[i] - m1[i]) - xh[i] * m2[i]);
@@ -404,6 +437,14 @@ size_t workspace_need(const BnGeo &gs, const BnGeo &ga)
     return p + 4 * (size_t)gs.G * gs.C * sizeof(float);
 }
 
+// pool: 0 none | 1 pairs (even L) | 2 whole row (L a power of two in 4 .. 256)
+bool pool_ok(int pool, int L)
+{
+    if (pool == 0) return true;
+    if (pool == 1) return (L & 1) == 0;
+    return pool == 2 && L >= 4 && (L & (L - 1)) == 0;
+}
+
 }  // namespace
 
 extern "C" size_t pof_bn_lrelu_pool_workspace_bytes(long long S, int C, int L, int groups)
@@ -425,7 +466,7 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
     BnGeo gs, ga;
     if (!make_geo(S, C, L, groups, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, groups, kStreamWgs, kStreamK, &ga))
         return POF_E_SHAPE;
-    if (pool && (L & 1)) return POF_E_SHAPE;
+    if (!pool_ok(pool, L)) return POF_E_SHAPE;
     if (!(eps >= 0.0)) return POF_E_BADARG;
     if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
@@ -438,8 +479,9 @@ extern "C" int pof_bn_lrelu_pool_forward(const float *y, long long S, int C, int
                                                  save_mean, save_invstd, scale, shift);
     POF_CHECK_LAUNCH();
     const dim3 grid((unsigned)ga.nchunk, ga.nslice);
-    if (pool) bn_apply_kernel<true><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
-    else bn_apply_kernel<false><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
+    if (pool == 2) bn_apply_kernel<2><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
+    else if (pool) bn_apply_kernel<1><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
+    else bn_apply_kernel<0><<<grid, kBnThreads, 0, st>>>(y, ga, scale, shift, (float)negative_slope, out);
     POF_CHECK_LAUNCH();
     return POF_OK;
 }
@@ -456,7 +498,7 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     BnGeo gs, ga;
     if (!make_geo(S, C, L, groups, kStatsWgs, kStatsK, &gs) || !make_geo(S, C, L, groups, kStreamWgs, kStreamK, &ga))
         return POF_E_SHAPE;
-    if (pool && (L & 1)) return POF_E_SHAPE;
+    if (!pool_ok(pool, L)) return POF_E_SHAPE;
     if (workspace_bytes < workspace_need(gs, ga)) return POF_E_WORKSPACE;
     double2 *partial = static_cast<double2 *>(workspace);
     float *coef = reinterpret_cast<float *>(static_cast<char *>(workspace) + workspace_need(gs, ga)) - 4 * groups * C;
@@ -464,15 +506,16 @@ extern "C" int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long 
     const float slope = (float)negative_slope;
     hipStream_t st = pof_stream(stream);
     const dim3 rgrid((unsigned)gs.nchunk, gs.nslice), dgrid((unsigned)ga.nchunk, ga.nslice);
-    if (pool) bn_bwd_reduce_kernel<true><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
-    else bn_bwd_reduce_kernel<false><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial);
+#define POF_REDUCE(P_) bn_bwd_reduce_kernel<P_><<<rgrid, kBnThreads, 0, st>>>(y, dz, gs, gamma, beta, save_mean, save_invstd, slope, partial)
+    if (pool == 2) POF_REDUCE(2); else if (pool) POF_REDUCE(1); else POF_REDUCE(0);
+#undef POF_REDUCE
     POF_CHECK_LAUNCH();
     bn_bwd_final_kernel<<<C, kBnThreads, 0, st>>>(partial, gs, dgamma, dbeta, k1, k2);
     POF_CHECK_LAUNCH();
 #define POF_DGRAD(P_, D_) bn_bwd_dgrad_kernel<P_, D_><<<dgrid, kBnThreads, 0, st>>>( \
         y, dz, ga, gamma, beta, save_mean, save_invstd, k1, k2, slope, dy, partial)
-    if (dbias_in) { if (pool) POF_DGRAD(true, true); else POF_DGRAD(false, true); }
-    else { if (pool) POF_DGRAD(true, false); else POF_DGRAD(false, false); }
+    if (dbias_in) { if (pool == 2) POF_DGRAD(2, true); else if (pool) POF_DGRAD(1, true); else POF_DGRAD(0, true); }
+    else { if (pool == 2) POF_DGRAD(2, false); else if (pool) POF_DGRAD(1, false); else POF_DGRAD(0, false); }
 #undef POF_DGRAD
     POF_CHECK_LAUNCH();
     if (dbias_in) {

@@ -91,11 +91,14 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
 template <int CT, int KW, int STRIDE>
 __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
 {
-    constexpr int kRows = KW * kCvCC;                  // K rows per chunk (tap-major)
+    // input channels per LDS weight chunk: 4 x 3 taps = 12 K rows, or 16 x 1 tap -- the point-wise form would otherwise
+    // meet a workgroup barrier every two k-steps (1024 -> 128, 64 positions x 256 sequences: 145 -> see DESIGN us)
+    constexpr int CC = KW == 1 ? 16 : kCvCC;
+    constexpr int kRows = KW * CC;                  // K rows per chunk (tap-major)
     constexpr int kPad = KW / 2;
     constexpr int COG = 32 * CT;                       // output channels per workgroup
     constexpr int NT = 64 * kCvWaves;
-    constexpr int NP = kCvCC / 2;                      // channel pairs (k-steps) per tap and chunk
+    constexpr int NP = CC / 2;                      // channel pairs (k-steps) per tap and chunk
     __shared__ __attribute__((aligned(16))) float s_w[2][kRows][COG];   // double-buffered weight chunk
     __shared__ __attribute__((aligned(16))) float s_scale[COG], s_shift[COG];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
         off_0[tap] = (base_off + (tap_ok[tap] ? tap - kPad : 0)) * 4u;
         off_h[tap] = off_0[tap] + (unsigned)(h * a.L) * 4u;
     }
-    const int nchunk = (a.Ci + kCvCC - 1) / kCvCC;
+    const int nchunk = (a.Ci + CC - 1) / CC;
 
     // weight chunk -> registers (16-byte loads along co; uniform chunk base + per-thread byte offsets
     // that do not change from chunk to chunk), registers -> LDS
@@ -138,19 +141,19 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
     using F4V = float __attribute__((ext_vector_type(4)));
     F4V wreg[WV];
     unsigned woff[WV];      // ((tap * Ci + cl) * Co + c) * 4 bytes
-    int wcl[WV];            // cl, or kCvCC when the group is outside the tile / the tensor
+    int wcl[WV];            // cl, or CC when the group is outside the tile / the tensor
     const bool wvec = (a.Co & 3) == 0;
 #pragma unroll
     for (int q = 0; q < WV; ++q) {
         const int e4 = threadIdx.x + q * NT;
         const int row = e4 / (COG / 4), c = (e4 - row * (COG / 4)) * 4;
-        const int tap = row / kCvCC, cl = row - tap * kCvCC;
+        const int tap = row / CC, cl = row - tap * CC;
         const bool in = e4 < kRows * COG / 4 && co0 + c < a.Co;
         woff[q] = in ? (unsigned)(((long long)tap * a.Ci + cl) * a.Co + c) * 4u : 0u;
-        wcl[q] = in ? cl : kCvCC;
+        wcl[q] = in ? cl : CC;
     }
     auto load_w = [&](int ci0) {
-        const int cc = min(kCvCC, a.Ci - ci0);
+        const int cc = min(CC, a.Ci - ci0);
         const char *wbase = reinterpret_cast<const char *>(a.wt + (long long)ci0 * a.Co + co0);   // uniform
 #pragma unroll
         for (int q = 0; q < WV; ++q) {
@@ -178,7 +181,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
     // activation operands of one chunk: 3 taps x NP channel pairs, uniform row base + lane offset
     float xb[2][KW][NP];
     auto load_x = [&](int set, int ci0) {
-        const int cc = min(kCvCC, a.Ci - ci0);
+        const int cc = min(CC, a.Ci - ci0);
 #pragma unroll
         for (int tap = 0; tap < KW; ++tap)
 #pragma unroll
@@ -200,12 +203,12 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
     __syncthreads();
     auto chunk = [&](auto set_tag, const int ch) {
         constexpr int SET = decltype(set_tag)::value;          // activation set / LDS buffer of this chunk
-        const int ci0 = ch * kCvCC;
-        const int cc = min(kCvCC, a.Ci - ci0);
+        const int ci0 = ch * CC;
+        const int cc = min(CC, a.Ci - ci0);
         const bool more = ch + 1 < nchunk;
         if (more) {                       // next chunk's weights and activations are in flight during the MFMAs
-            load_w(ci0 + kCvCC);
-            load_x(SET ^ 1, ci0 + kCvCC);
+            load_w(ci0 + CC);
+            load_x(SET ^ 1, ci0 + CC);
         }
         // A operand one k-step ahead of its MFMAs
         float a_cur[CT], a_nxt[CT];
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
             if (ks + 1 < KW * NP) {
                 const int tn = (ks + 1) / NP, pn = (ks + 1) - tn * NP;
 #pragma unroll
-                for (int t = 0; t < CT; ++t) a_nxt[t] = s_w[SET][tn * kCvCC + 2 * pn + h][t * 32 + r];
+                for (int t = 0; t < CT; ++t) a_nxt[t] = s_w[SET][tn * CC + 2 * pn + h][t * 32 + r];
             }
             __builtin_amdgcn_sched_barrier(0);
             const bool ok = tap_ok[tap] && (2 * p + h < cc);

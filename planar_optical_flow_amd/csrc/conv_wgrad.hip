@@ -97,8 +97,10 @@ struct StageTile {
 
 // WM = waves along the output channels: 4 -> tile 128 co, a wave owns both 32-channel halves of the ci tile;
 // 2 -> tile 64 co, a wave owns one half.  V = floats per global load (4 / 2 / 1 by the row length's alignment).
-template <int WM, int V>
-__global__ __launch_bounds__(kWgThreads, 2) void conv3_wgrad_kernel(WgradArgs a)
+// TAPS = 3: the kernel-3 convolution above.  TAPS = 1: the point-wise convolution (dw[co][ci] = sum dy[co][l] x[ci][l]):
+// the x row carries no leading zero and a k-step is one MFMA per accumulator.
+template <int WM, int V, int TAPS>
+__global__ __launch_bounds__(kWgThreads, 2) void conv_wgrad_kernel(WgradArgs a)
 {
     constexpr int MT_LOG2 = WM == 4 ? 7 : 6, MT = 1 << MT_LOG2;
     constexpr int NSUB = WM == 4 ? 2 : 1;
@@ -128,18 +130,18 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv3_wgrad_kernel(WgradArgs a)
     const int mn = lane & 31, kk = lane >> 5;
     const int wm_idx = WM == 4 ? w : (w & 1), wn_idx = WM == 4 ? 0 : (w >> 1);
 
-    float16v acc[NSUB][3];
+    float16v acc[NSUB][TAPS];
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < TAPS; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[sub][t][v] = 0.0f;
 
     for (int s0 = s_begin; s0 < s_end; s0 += a.G) {
         __syncthreads();        // the previous stage's operands are consumed (and, the first time, LDS is zeroed)
         td.commit(lds_d, a.sd, 0, a.L, a.G, a.tpr_log2);
-        tx.commit(lds_x, a.sx, 1, a.L, a.G, a.tpr_log2);
+        tx.commit(lds_x, a.sx, TAPS == 3 ? 1 : 0, a.L, a.G, a.tpr_log2);
         __syncthreads();
         if (s0 + a.G < s_end) {     // the next stage's loads fly during this stage's MFMAs
             td.issue(a.dy, a.Co, a.L, co0, s0 + a.G, s_end, a.G, a.tpr_log2);
@@ -159,38 +161,53 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv3_wgrad_kernel(WgradArgs a)
                 b2[sub] = pb[sub][2];
                 b3[sub] = pb[sub][3];
             }
-            for (int i = 0; i < a.Lh; ++i) {
-                // operands of the NEXT k-step first (the row's zero tail makes the read past the last step harmless),
-                // then this step's MFMAs: the LDS latency hides behind them
-                const float an = pa[2 * i + 2];
-                float n2[NSUB], n3[NSUB];
+            if constexpr (TAPS == 3) {
+                for (int i = 0; i < a.Lh; ++i) {
+                    // operands of the NEXT k-step first (the row's zero tail makes the read past the last step
+                    // harmless), then this step's MFMAs: the LDS latency hides behind them
+                    const float an = pa[2 * i + 2];
+                    float n2[NSUB], n3[NSUB];
 #pragma unroll
-                for (int sub = 0; sub < NSUB; ++sub) {
-                    n2[sub] = pb[sub][2 * i + 4];
-                    n3[sub] = pb[sub][2 * i + 5];
-                }
+                    for (int sub = 0; sub < NSUB; ++sub) {
+                        n2[sub] = pb[sub][2 * i + 4];
+                        n3[sub] = pb[sub][2 * i + 5];
+                    }
 #pragma unroll
-                for (int sub = 0; sub < NSUB; ++sub) {
-                    acc[sub][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[sub], acc[sub][0], 0, 0, 0);
-                    acc[sub][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[sub], acc[sub][1], 0, 0, 0);
-                    acc[sub][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2[sub], acc[sub][2], 0, 0, 0);
-                    b0[sub] = b2[sub];      // tap 0 of the next k-step (positions + 2) is tap 2 of this one
-                    b1[sub] = b3[sub];
-                    b2[sub] = n2[sub];
-                    b3[sub] = n3[sub];
+                    for (int sub = 0; sub < NSUB; ++sub) {
+                        acc[sub][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[sub], acc[sub][0], 0, 0, 0);
+                        acc[sub][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1[sub], acc[sub][1], 0, 0, 0);
+                        acc[sub][2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b2[sub], acc[sub][2], 0, 0, 0);
+                        b0[sub] = b2[sub];      // tap 0 of the next k-step (positions + 2) is tap 2 of this one
+                        b1[sub] = b3[sub];
+                        b2[sub] = n2[sub];
+                        b3[sub] = n3[sub];
+                    }
+                    av = an;
                 }
-                av = an;
+            } else {
+                for (int i = 0; i < a.Lh; ++i) {
+                    const float an = pa[2 * i + 2];
+                    float n0[NSUB];
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub) n0[sub] = pb[sub][2 * i + 2];
+#pragma unroll
+                    for (int sub = 0; sub < NSUB; ++sub) {
+                        acc[sub][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0[sub], acc[sub][0], 0, 0, 0);
+                        b0[sub] = n0[sub];
+                    }
+                    av = an;
+                }
             }
         }
     }
 
     // partial[split][tap][co][ci]: the 32 lanes of a row write 128 contiguous bytes
-    float *out = a.partial + (long long)split * 3 * a.Co * a.Ci;
+    float *out = a.partial + (long long)split * TAPS * a.Co * a.Ci;
 #pragma unroll
     for (int sub = 0; sub < NSUB; ++sub) {
         const int ci = ci0 + 32 * (wn_idx * NSUB + sub) + mn;
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < TAPS; ++t)
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int co = co0 + 32 * wm_idx + (v & 3) + 8 * (v >> 2) + 4 * kk;
@@ -201,31 +218,33 @@ __global__ __launch_bounds__(kWgThreads, 2) void conv3_wgrad_kernel(WgradArgs a)
 
 // dw[co][ci][t] = sum over splits (float64 accumulation).  32 consecutive weights x 8 groups of splits per
 // workgroup: a few hundred splits of a small layer (64 x 64 weights) would otherwise be one serial chain per thread
-__global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, int Co,
-                                                                 int Ci, float *__restrict__ dw)
+template <int TAPS>
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, int Co,
+                                                                int Ci, float *__restrict__ dw)
 {
-    __shared__ double s_part[8][3][32];
+    __shared__ double s_part[8][TAPS][32];
     const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
     const int e = blockIdx.x * 32 + el;
     const long long plane = (long long)Co * Ci;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    double s[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s[t] = 0.0;
     if (e < plane) {
-        const float *p = partial + e + (long long)grp * 3 * plane;
+        const float *p = partial + e + (long long)grp * TAPS * plane;
 #pragma unroll 4
-        for (int k = grp; k < nsplit; k += 8, p += 8 * 3 * plane) {
-            s0 += (double)p[0];
-            s1 += (double)p[plane];
-            s2 += (double)p[2 * plane];
-        }
+        for (int k = grp; k < nsplit; k += 8, p += 8 * TAPS * plane)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) s[t] += (double)p[t * plane];
     }
-    s_part[grp][0][el] = s0; s_part[grp][1][el] = s1; s_part[grp][2][el] = s2;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) s_part[grp][t][el] = s[t];
     __syncthreads();
-    if (threadIdx.x < 96) {
+    if (threadIdx.x < 32 * TAPS) {
         const int t = threadIdx.x >> 5;
         double acc = 0.0;
 #pragma unroll
         for (int g = 0; g < 8; ++g) acc += s_part[g][t][el];
-        if (e < plane) dw[3 * (long long)e + t] = (float)acc;
+        if (e < plane) dw[TAPS * (long long)e + t] = (float)acc;
     }
 }
 
@@ -272,39 +291,64 @@ bool make_wgrad(int S, int Ci, int Co, int L, bool aligned, WgradArgs *a, int *w
 
 }  // namespace
 
-extern "C" size_t pof_conv3_wgrad_workspace_bytes(int S, int Ci, int Co, int L)
-{
-    WgradArgs a;
-    int wm;
-    size_t lds;
-    if (!make_wgrad(S, Ci, Co, L, true, &a, &wm, &lds)) return 0;
-    return (size_t)a.nsplit * 3 * (size_t)Co * Ci * sizeof(float);
-}
+namespace {
 
-extern "C" int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, float *dw,
-                               void *workspace, size_t workspace_bytes, pof_stream_t stream)
+int run_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, int taps, float *dw, void *workspace,
+              size_t workspace_bytes, pof_stream_t stream)
 {
     POF_CLEAR_STALE_ERROR();
     if (!x || !dy || !dw || !workspace) return POF_E_BADARG;
-    if (S < 1 || Ci < 1 || Co < 1 || L < 1) return POF_E_BADARG;
+    if (S < 1 || Ci < 1 || Co < 1 || L < 1 || (taps != 1 && taps != 3)) return POF_E_BADARG;
     if ((long long)S * Ci * L >= (1LL << 31) * 4 || (long long)Co * Ci >= (1LL << 28)) return POF_E_SHAPE;
     const bool aligned = ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
     WgradArgs a;
     int wm;
     size_t lds;
     if (!make_wgrad(S, Ci, Co, L, aligned, &a, &wm, &lds)) return POF_E_SHAPE;
-    if (workspace_bytes < (size_t)a.nsplit * 3 * (size_t)Co * Ci * sizeof(float)) return POF_E_WORKSPACE;
+    if (workspace_bytes < (size_t)a.nsplit * taps * (size_t)Co * Ci * sizeof(float)) return POF_E_WORKSPACE;
     a.x = x; a.dy = dy; a.partial = static_cast<float *>(workspace);
     hipStream_t st = pof_stream(stream);
-    const int MT = wm == 4 ? 128 : 64;
-    (void)MT;
     const dim3 grid((unsigned)((a.nsplit + 7) / 8 * 8 * a.tiles));
-#define POF_WGRAD(WM_, V_) conv3_wgrad_kernel<WM_, V_><<<grid, kWgThreads, lds, st>>>(a)
-    if (wm == 4) { if (a.vec == 4) POF_WGRAD(4, 4); else if (a.vec == 2) POF_WGRAD(4, 2); else POF_WGRAD(4, 1); }
-    else { if (a.vec == 4) POF_WGRAD(2, 4); else if (a.vec == 2) POF_WGRAD(2, 2); else POF_WGRAD(2, 1); }
+#define POF_WGRAD(WM_, V_, T_) conv_wgrad_kernel<WM_, V_, T_><<<grid, kWgThreads, lds, st>>>(a)
+#define POF_WGRAD_V(WM_, T_) \
+    do { if (a.vec == 4) POF_WGRAD(WM_, 4, T_); else if (a.vec == 2) POF_WGRAD(WM_, 2, T_); else POF_WGRAD(WM_, 1, T_); } while (0)
+    if (taps == 3) { if (wm == 4) POF_WGRAD_V(4, 3); else POF_WGRAD_V(2, 3); }
+    else           { if (wm == 4) POF_WGRAD_V(4, 1); else POF_WGRAD_V(2, 1); }
+#undef POF_WGRAD_V
 #undef POF_WGRAD
     POF_CHECK_LAUNCH();
-    conv3_wgrad_reduce_kernel<<<(Co * Ci + 31) / 32, 256, 0, st>>>(a.partial, a.nsplit, Co, Ci, dw);
+    if (taps == 3) conv_wgrad_reduce_kernel<3><<<(Co * Ci + 31) / 32, 256, 0, st>>>(a.partial, a.nsplit, Co, Ci, dw);
+    else conv_wgrad_reduce_kernel<1><<<(Co * Ci + 31) / 32, 256, 0, st>>>(a.partial, a.nsplit, Co, Ci, dw);
     POF_CHECK_LAUNCH();
     return POF_OK;
+}
+
+size_t wgrad_workspace(int S, int Ci, int Co, int L, int taps)
+{
+    WgradArgs a;
+    int wm;
+    size_t lds;
+    if ((taps != 1 && taps != 3) || !make_wgrad(S, Ci, Co, L, true, &a, &wm, &lds)) return 0;
+    return (size_t)a.nsplit * taps * (size_t)Co * Ci * sizeof(float);
+}
+
+}  // namespace
+
+extern "C" size_t pof_conv3_wgrad_workspace_bytes(int S, int Ci, int Co, int L) { return wgrad_workspace(S, Ci, Co, L, 3); }
+
+extern "C" int pof_conv3_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, float *dw,
+                               void *workspace, size_t workspace_bytes, pof_stream_t stream)
+{
+    return run_wgrad(x, dy, S, Ci, Co, L, 3, dw, workspace, workspace_bytes, stream);
+}
+
+extern "C" size_t pof_conv1d_wgrad_workspace_bytes(int S, int Ci, int Co, int L, int kernel_size)
+{
+    return wgrad_workspace(S, Ci, Co, L, kernel_size);
+}
+
+extern "C" int pof_conv1d_wgrad(const float *x, const float *dy, int S, int Ci, int Co, int L, int kernel_size,
+                                float *dw, void *workspace, size_t workspace_bytes, pof_stream_t stream)
+{
+    return run_wgrad(x, dy, S, Ci, Co, L, kernel_size, dw, workspace, workspace_bytes, stream);
 }

@@ -496,32 +496,63 @@ def drow_heads(feat, w_cls, b_cls, w_reg, b_reg):
     return pred_cls, pred_reg
 
 
-def conv3_wgrad_supported(S, Ci, Co, L):
-    return S > 0 and int(_lib.load().pof_conv3_wgrad_workspace_bytes(int(S), int(Ci), int(Co), int(L))) > 0
+def conv3_wgrad_supported(S, Ci, Co, L, kernel_size=3):
+    return S > 0 and int(_lib.load().pof_conv1d_wgrad_workspace_bytes(int(S), int(Ci), int(Co), int(L),
+                                                                      int(kernel_size))) > 0
 
 
-def conv3_wgrad(x, dy):
-    """N2 training: weight gradient of Conv1d(k=3, pad=1): x [S,Ci,L] f32, dy [S,Co,L] f32 -> dw [Co,Ci,3] f32."""
+def conv3_wgrad(x, dy, kernel_size=3):
+    """N2 training: weight gradient of Conv1d(k = 3 | 1, pad = k // 2): x [S,Ci,L] f32, dy [S,Co,L] f32 ->
+    dw [Co,Ci,k] f32."""
     x = _dev(x, torch.float32, "x")
     dy = _dev(dy, torch.float32, "dy")
     S, Ci, L = x.shape
     if dy.dim() != 3 or dy.shape[0] != S or dy.shape[2] != L:
         raise ValueError("dy must be [S, Co, L]")
+    if kernel_size not in (1, 3):
+        raise ValueError("kernel_size must be 1 or 3")
     Co = dy.shape[1]
-    nbytes = int(_lib.load().pof_conv3_wgrad_workspace_bytes(S, Ci, Co, L))
+    nbytes = int(_lib.load().pof_conv1d_wgrad_workspace_bytes(S, Ci, Co, L, kernel_size))
     if nbytes == 0:
         raise ValueError("conv3_wgrad: unsupported shape S=%d Ci=%d Co=%d L=%d" % (S, Ci, Co, L))
     ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x.device)
-    dw = torch.empty((Co, Ci, 3), dtype=torch.float32, device=x.device)
+    dw = torch.empty((Co, Ci, kernel_size), dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        _lib.call("pof_conv3_wgrad", _ptr(x), _ptr(dy), S, Ci, Co, L, _ptr(dw), _ptr(ws), nbytes, _stream())
+        _lib.call("pof_conv1d_wgrad", _ptr(x), _ptr(dy), S, Ci, Co, L, kernel_size, _ptr(dw), _ptr(ws), nbytes,
+                  _stream())
     return dw
 
 
+def linear_bias(x, weight, bias=None, out=None):
+    """configs[3] dense layers: x [B,K] f32, weight [N,K] f32 (torch.nn.Linear's), bias [N] f32 or None -> x @ weight.T
+    + bias [B,N] on the small-batch MFMA kernel (K a multiple of 4)."""
+    x = _dev(x, torch.float32, "x")
+    weight = _dev(weight, torch.float32, "weight")
+    if x.dim() != 2 or weight.dim() != 2 or weight.shape[1] != x.shape[1]:
+        raise ValueError("x must be [B, K] and weight [N, K]")
+    B, K = x.shape
+    N = weight.shape[0]
+    if K % 4:
+        raise ValueError("linear_bias: K = %d is not a multiple of 4" % K)
+    if bias is not None and _dev(bias, torch.float32, "bias").numel() != N:
+        raise ValueError("bias must have N entries")
+    if out is None:
+        out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    elif tuple(out.shape) != (B, N) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != x.device:
+        raise ValueError("out must be a contiguous float32 [B, N] tensor on x's device")
+    if B == 0:
+        return out
+    with torch.cuda.device(x.device):
+        _lib.call("pof_linear_bias", _ptr(x), _ptr(weight), _ptr(bias), B, K, N, _ptr(out), _stream())
+    return out
+
+
 def bn_lrelu_pool_supported(S, C, L, pool=False, groups=1):
-    """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, L even when pooled,
-    S % groups == 0)."""
-    if pool and (L & 1):
+    """True when the fused training tail covers this shape (L <= 256, C*L % 4 == 0, S % groups == 0; pool = True / 1:
+    max over pairs, L even; pool = 2: max over the whole row, L a power of two >= 4)."""
+    if int(pool) == 1 and (L & 1):
+        return False
+    if int(pool) == 2 and (L < 4 or L & (L - 1)):
         return False
     return S > 0 and int(_lib.load().pof_bn_lrelu_pool_workspace_bytes(int(S), int(C), int(L), int(groups))) > 0
 
@@ -539,7 +570,8 @@ def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, m
     """N2 training tail: y [S,C,L] f32 (convolution output) -> (z [S,C,L or L//2], save_mean [groups*C],
     save_invstd [groups*C]); z = max_pool1d?(leaky_relu(batch_norm_train(y))), the batch statistics taken separately
     over each of `groups` equal contiguous ranges of the sequences.  running_mean / running_var are updated in
-    place (once per group, in order)."""
+    place (once per group, in order).  pool = 2: the maximum over the whole row, z [S,C] (the PointNet's max over
+    points)."""
     y = _dev(y, torch.float32, "y")
     gamma = _dev(gamma, torch.float32, "gamma")
     beta = _dev(beta, torch.float32, "beta")
@@ -550,13 +582,16 @@ def bn_lrelu_pool_forward(y, gamma, beta, running_mean=None, running_var=None, m
         if t is not None and (_dev(t, torch.float32, name).numel() != C):
             raise ValueError("%s must have C entries" % name)
     ws, nbytes = _bn_workspace(S, C, L, groups, y.device)
-    out = torch.empty((S, C, L // 2 if pool else L), dtype=torch.float32, device=y.device)
+    pool = int(pool)
+    if not bn_lrelu_pool_supported(S, C, L, pool, groups):
+        raise ValueError("bn_lrelu_pool: pool mode %d does not take L = %d" % (pool, L))
+    out = torch.empty((S, C) if pool == 2 else (S, C, L // 2 if pool else L), dtype=torch.float32, device=y.device)
     mean = torch.empty(groups * C, dtype=torch.float32, device=y.device)
     invstd = torch.empty(groups * C, dtype=torch.float32, device=y.device)
     with torch.cuda.device(y.device):
         _lib.call("pof_bn_lrelu_pool_forward", _ptr(y), S, C, L, int(groups), _ptr(gamma), _ptr(beta),
                   _ptr(running_mean), _ptr(running_var), float(momentum), float(eps), float(negative_slope),
-                  int(bool(pool)), _ptr(out), _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream())
+                  pool, _ptr(out), _ptr(mean), _ptr(invstd), _ptr(ws), nbytes, _stream())
     return out, mean, invstd
 
 
@@ -567,8 +602,11 @@ def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_
     y = _dev(y, torch.float32, "y")
     dz = _dev(dz, torch.float32, "dz")
     S, C, L = y.shape
-    if tuple(dz.shape) != (S, C, L // 2 if pool else L):
-        raise ValueError("dz must be [S, C, %s]" % ("L//2" if pool else "L"))
+    pool = int(pool)
+    if not bn_lrelu_pool_supported(S, C, L, pool, groups):
+        raise ValueError("bn_lrelu_pool: pool mode %d does not take L = %d" % (pool, L))
+    if tuple(dz.shape) != ((S, C) if pool == 2 else (S, C, L // 2 if pool else L)):
+        raise ValueError("dz must be [S, C%s]" % ("" if pool == 2 else ", L//2" if pool else ", L"))
     for name, t, n in (("gamma", gamma, C), ("beta", beta, C), ("save_mean", save_mean, groups * C),
                        ("save_invstd", save_invstd, groups * C)):
         if _dev(t, torch.float32, name).numel() != n:
@@ -580,7 +618,7 @@ def bn_lrelu_pool_backward(y, dz, gamma, beta, save_mean, save_invstd, negative_
     dbias = torch.empty(C, dtype=torch.float32, device=y.device) if bias_grad else None
     with torch.cuda.device(y.device):
         _lib.call("pof_bn_lrelu_pool_backward", _ptr(y), _ptr(dz), S, C, L, int(groups), _ptr(gamma), _ptr(beta),
-                  _ptr(save_mean), _ptr(save_invstd), float(negative_slope), int(bool(pool)), _ptr(dy), _ptr(dgamma),
+                  _ptr(save_mean), _ptr(save_invstd), float(negative_slope), pool, _ptr(dy), _ptr(dgamma),
                   _ptr(dbeta), _ptr(dbias), _ptr(ws), nbytes, _stream())
     return (dy, dgamma, dbeta, dbias) if bias_grad else (dy, dgamma, dbeta)
 

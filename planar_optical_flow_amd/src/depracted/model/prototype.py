@@ -115,6 +115,36 @@ class Prototype(nn.Module):
         out = self._unit_hip("flow_reg", torch.cat((s1, self._upsample(out, size=s1.shape[-1])), dim=1))
         return out.permute(0, 2, 1)
 
+    hip_train = True    # training on the device: every unit through torch_ops.ConvUnitTrain (False: the torch modules)
+
+    def _unit_train(self, name, x, groups=1):
+        conv, bn, act = getattr(self, name)
+        if type(bn) is nn.BatchNorm1d and torch_ops.conv_unit_train_supported(conv, x.shape[2]):
+            return torch_ops.conv_unit_train(x, conv, bn, act.negative_slope, groups=groups)
+        if conv.kernel_size[0] == 1 and groups == 1:       # the point-wise head: HIP convolution, torch BatchNorm
+            return act(bn(torch_ops.Conv1dTrain.apply(x.contiguous().float(), conv.weight, conv.bias)))
+        if groups == 1:
+            return act(bn(conv(x)))
+        return torch.cat([act(bn(conv(part))) for part in x.chunk(groups, dim=0)], dim=0)
+
+    def _forward_train_hip(self, scan1, scan2):
+        """The training forward with every unit as one autograd node on the HIP kernels (convolution forward / data /
+        weight gradients + the fused BatchNorm(train) tail).  The two scans of a pair go through the encoders as two
+        statistics groups of one launch: each is normalised with its own batch statistics and the running statistics
+        are updated scan 1 first, then scan 2 -- what the reference's two calls per encoder do (prototype.py:70-80)."""
+        B = scan1.shape[0]
+        s1 = scan1.permute(0, 2, 1).contiguous().float()
+        f = torch.cat((s1, scan2.permute(0, 2, 1).contiguous().float()), dim=0)
+        skips = []
+        for name in ("encoder_0", "encoder_1", "encoder_2"):
+            f = self._unit_train(name, f, groups=2)
+            skips.append(f[:B])
+        out = self._fusion(f[:B], f[B:], max_displacement=self.max_displacement)
+        for name, skip in (("decoder_1", skips[1]), ("decoder_0", skips[0])):
+            out = self._unit_train(name, torch.cat((skip, self._upsample(out, size=skip.shape[-1])), dim=1))
+        out = self._unit_train("flow_reg", torch.cat((s1, self._upsample(out, size=s1.shape[-1])), dim=1))
+        return out.permute(0, 2, 1)
+
     def forward(self, scan1, scan2=None):
         """scan1, scan2 [B, n_pts, n_channel] -> per-point flow [B, n_pts, 2]."""
         if scan2 is None:
@@ -122,6 +152,8 @@ class Prototype(nn.Module):
         if getattr(self, "_fused", None) is not None and not self.training and scan1.is_cuda \
                 and not torch.is_grad_enabled():
             return self._forward_fused(scan1, scan2)
+        if self.training and scan1.is_cuda and self.hip_train:
+            return self._forward_train_hip(scan1, scan2)
         s1, s2 = scan1.permute(0, 2, 1), scan2.permute(0, 2, 1)
         skips, f1, f2 = [], s1, s2
         for enc in (self.encoder_0, self.encoder_1, self.encoder_2):

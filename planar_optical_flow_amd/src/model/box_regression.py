@@ -53,10 +53,25 @@ class PointNet(nn.Module):
 
     gemm_pointwise = True   # GPU inference: the 1x1 convolutions as library GEMMs over [B*n, C]
     train_pointwise = False  # the same form in training mode (autograd through F.linear / BatchNorm on [B*n, C])
+    hip_train = True        # GPU training: every unit one autograd node on the HIP kernels (torch_ops.ConvUnitTrain)
 
     def forward(self, x):  # x [B, C, n]
         if x.is_cuda and self.gemm_pointwise and (self.train_pointwise or not self.training):
             return self.forward_points(x.permute(0, 2, 1))
+        if x.is_cuda and self.training and self.hip_train and torch.is_grad_enabled():
+            from planar_optical_flow_amd import torch_ops
+            units = (self.conv1, self.conv2, self.conv3, self.conv4)
+            if all(type(u[1]) is nn.BatchNorm1d and torch_ops.conv_unit_train_supported(u[0], x.shape[2]) for u in units):
+                # (per-rank BatchNorm only: a SyncBatchNorm1d unit keeps the module path, whose statistics are global)
+                # float32-MFMA convolution + fused BatchNorm(train)/LeakyReLU tail forward; tail backward, data gradient
+                # on the same convolution kernel, weight gradient on the split-K kernel's one-tap form.  The library's
+                # path spends a third of its step on the weight-gradient kernels and their layout transposes.
+                n = x.shape[2]
+                fused_max = n >= 4 and n & (n - 1) == 0       # the max over points inside the last unit's tail
+                for u in units[:3]:
+                    x = torch_ops.conv_unit_train(x, u[0], u[1], u[2].negative_slope)
+                x = torch_ops.conv_unit_train(x, units[3][0], units[3][1], units[3][2].negative_slope, rowmax=fused_max)
+                return x if fused_max else torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
         x = self.conv4(self.conv3(self.conv2(self.conv1(x))))
         return torch.max(x, 2, keepdim=True)[0].view(-1, 1024)
 
@@ -97,11 +112,26 @@ class BoundingBoxRegressor(PointNet):
     def model_eval_fn(model, batch_data):
         return _model_eval_fn(model, batch_data)
 
+    small_batch_rows = 1024   # at most this many rows: the dense layers' forward on pof::linear_bias (GPU)
+
+    def _dense_forward(self, unit, x):
+        """fc1 / fc2 / fc3 on a batch of a few hundred rows: the BLAS library runs an output of at most 256 x 256 as one
+        tile on one CU (fc2: 118 us of a 0.9 ms training step); the small-batch MFMA kernel takes 32 x 32 tiles."""
+        if not (x.is_cuda and x.shape[0] <= self.small_batch_rows):
+            return unit(x)
+        from planar_optical_flow_amd import torch_ops
+        if isinstance(unit, nn.Linear):
+            return torch_ops.linear_small(x, unit)
+        x = torch_ops.linear_small(x, unit[0])
+        for layer in list(unit)[1:]:
+            x = layer(x)
+        return x
+
     def forward(self, x):  # x [B, n, C]
         bb = self.backbone
         x = bb.forward_points(x) if (x.is_cuda and bb.gemm_pointwise and (bb.train_pointwise or not self.training)) \
             else bb(x.permute(0, 2, 1))
-        x = self.fc2(self.fc1(x))
+        x = self._dense_forward(self.fc2, self._dense_forward(self.fc1, x))
         if self.dropout > 0.0:
             x = F.dropout(x, p=self.dropout, training=self.training)
-        return self.fc3(x)
+        return self._dense_forward(self.fc3, x)

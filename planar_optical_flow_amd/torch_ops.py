@@ -20,6 +20,7 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
         float momentum, float eps, float negative_slope, bool pool, int groups=1)
         -> (Tensor z, Tensor mean, Tensor invstd)
     pof::conv3_wgrad(Tensor x, Tensor dy) -> Tensor
+    pof::linear_bias(Tensor x, Tensor weight, Tensor? bias) -> Tensor
     pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
         float negative_slope, bool pool, bool bias_grad, int groups=1) -> (Tensor, Tensor, Tensor, Tensor)
 """
@@ -152,6 +153,55 @@ def _(x, wt, scale, shift, pool, negative_slope):
     return x.new_empty((S, wt.shape[2], L // 2 if pool else L))
 
 
+@torch.library.custom_op("pof::conv1d_bn_lrelu", mutates_args=(), device_types="cuda")
+def conv1d_bn_lrelu(x: torch.Tensor, wt: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride: int,
+                    negative_slope: float) -> torch.Tensor:
+    return ops.conv1d_bn_lrelu(x.contiguous(), wt, scale, shift, stride=stride, negative_slope=negative_slope)
+
+
+@conv1d_bn_lrelu.register_fake
+def _(x, wt, scale, shift, stride, negative_slope):
+    S, _, L = x.shape
+    return x.new_empty((S, wt.shape[2], (L + stride - 1) // stride))
+
+
+@torch.library.custom_op("pof::linear_bias", mutates_args=(), device_types="cuda")
+def linear_bias(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    return ops.linear_bias(x.contiguous(), weight.contiguous(), bias)
+
+
+@linear_bias.register_fake
+def _(x, weight, bias):
+    return x.new_empty((x.shape[0], weight.shape[0]))
+
+
+def _linear_setup(ctx, inputs, output):
+    x, weight, bias = inputs
+    ctx.save_for_backward(x, weight)
+    ctx.has_bias = bias is not None
+
+
+def _linear_backward(ctx, g):
+    # the two backward GEMMs (outputs B x K and N x K) are shapes the BLAS library runs well
+    x, weight = ctx.saved_tensors
+    dx = g.mm(weight) if ctx.needs_input_grad[0] else None
+    dw = g.t().mm(x) if ctx.needs_input_grad[1] else None
+    db = g.sum(dim=0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+    return dx, dw, db
+
+
+linear_bias.register_autograd(_linear_backward, setup_context=_linear_setup)
+
+
+def linear_small(x, linear):
+    """``linear(x)`` for a ``torch.nn.Linear`` on a small batch (the box head's dense layers): the forward on
+    ``pof::linear_bias`` when the shape allows (2-D float32 input on the device, in_features a multiple of 4)."""
+    if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and linear.in_features % 4 == 0 \
+            and linear.weight.dtype == torch.float32:
+        return torch.ops.pof.linear_bias(x, linear.weight, linear.bias)
+    return linear(x)
+
+
 # ------------------------------------------------------------------------------------------------- N2 (training)
 @torch.library.custom_op("pof::bn_lrelu_pool", mutates_args=("running_mean", "running_var"), device_types="cuda")
 def bn_lrelu_pool(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
@@ -182,6 +232,40 @@ def bn_lrelu_pool_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tenso
 
 @bn_lrelu_pool_backward.register_fake
 def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool, bias_grad, groups=1):
+    return (torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta),
+            gamma.new_empty((gamma.shape[0] if bias_grad else 0,)))
+
+
+@torch.library.custom_op("pof::bn_lrelu_rowmax", mutates_args=("running_mean", "running_var"), device_types="cuda")
+def bn_lrelu_rowmax(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
+                    running_var: Optional[torch.Tensor], momentum: float, eps: float, negative_slope: float,
+                    groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """max over the row of leaky_relu(batch_norm_train(y)): y [S,C,L] -> z [S,C] (the PointNet's max over points fused
+    into the tail's apply pass: the activation is never written)."""
+    z, mean, invstd = ops.bn_lrelu_pool_forward(y.contiguous(), gamma.contiguous(), beta.contiguous(), running_mean,
+                                                running_var, momentum, eps, negative_slope, 2, groups=groups)
+    return z, mean, invstd
+
+
+@bn_lrelu_rowmax.register_fake
+def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, groups=1):
+    S, C, L = y.shape
+    return (y.new_empty((S, C)), y.new_empty((groups * C,)), y.new_empty((groups * C,)))
+
+
+@torch.library.custom_op("pof::bn_lrelu_rowmax_backward", mutates_args=(), device_types="cuda")
+def bn_lrelu_rowmax_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
+                             mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, bias_grad: bool,
+                             groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+    res = ops.bn_lrelu_pool_backward(y, dz.contiguous().float(), gamma.contiguous(), beta.contiguous(), mean, invstd,
+                                     negative_slope, 2, bias_grad=bias_grad, groups=groups)
+    if bias_grad:
+        return res
+    return res[0], res[1], res[2], gamma.new_empty((0,))
+
+
+@bn_lrelu_rowmax_backward.register_fake
+def _(y, dz, gamma, beta, mean, invstd, negative_slope, bias_grad, groups=1):
     return (torch.empty_like(y), torch.empty_like(gamma), torch.empty_like(beta),
             gamma.new_empty((gamma.shape[0] if bias_grad else 0,)))
 
@@ -242,10 +326,79 @@ def _(x, dy):
     return x.new_empty((dy.shape[1], x.shape[1], 3))
 
 
+@torch.library.custom_op("pof::conv1_wgrad", mutates_args=(), device_types="cuda")
+def conv1_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    return ops.conv3_wgrad(x.contiguous(), dy.contiguous(), kernel_size=1)
+
+
+@conv1_wgrad.register_fake
+def _(x, dy):
+    return x.new_empty((dy.shape[1], x.shape[1], 1))
+
+
+def _wgrad_supported(S, ci, co, L, k):
+    """Shapes the split-K weight-gradient kernel stages in LDS -- the arithmetic of make_wgrad() in csrc/conv_wgrad.hip
+    restated in plain Python, so that torch.compile can evaluate it on symbolic sizes (a ctypes query of the C ABI
+    cannot be traced inside an autograd.Function).  tests/test_abi.py holds the two against each other over a sweep."""
+    if S < 1 or ci < 1 or co < 1 or L < 1 or L > 256 or k not in (1, 3):
+        return False
+    lh = (L + 1) // 2
+    mt = 128 if co > 64 else 64
+    per_seq = (mt * (2 * lh + 3) + 64 * (2 * lh + 5)) * 4
+    vec = 4 if L % 4 == 0 else (2 if L % 2 == 0 else 1)
+    per_row = (L + vec - 1) // vec
+    tpr_log2 = 0
+    while (1 << tpr_log2) < per_row:
+        tpr_log2 += 1
+    if tpr_log2 > 8:
+        return False
+    stage = {4: 32, 2: 24, 1: 16}[vec]
+    max_g = (stage // vec) * (256 >> tpr_log2) // 128
+    if max_g < 1:
+        return False
+    g = max(1, min(8, 48 * 1024 // per_seq, max_g))
+    if g * per_seq > 64 * 1024:
+        return False
+    tiles = ((co + mt - 1) // mt) * ((ci + 63) // 64)
+    return tiles <= 65535
+
+
+def _pointwise_weight_grad(x, dy, weight):
+    """dL/dweight of the k = 1 convolution, dw[co][ci] = sum dy[s][co][l] x[s][ci][l]: the split-K MFMA kernel's
+    one-tap form; rows too long for its LDS stage are cut into chunks (no halo: positions do not interact)."""
+    S, ci, L = (int(v) for v in x.shape)       # (int: a symbolic size under torch.compile is specialised here)
+    co = int(dy.shape[1])
+    if _wgrad_supported(S, ci, co, L, 1):
+        return torch.ops.pof.conv1_wgrad(x, dy)
+    for lc in (64, 56, 48, 40, 32, 24, 16):
+        nc = -(-L // lc)
+        if _wgrad_supported(S * nc, ci, co, lc, 1):
+            pad = nc * lc - L
+            xc = torch.nn.functional.pad(x, (0, pad)).reshape(S, ci, nc, lc).permute(0, 2, 1, 3).reshape(S * nc, ci, lc)
+            dyc = torch.nn.functional.pad(dy, (0, pad)).reshape(S, co, nc, lc).permute(0, 2, 1, 3).reshape(S * nc, co, lc)
+            return torch.ops.pof.conv1_wgrad(xc.contiguous(), dyc.contiguous())
+    return torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [0], [1], False, [0], 1,
+                                               [False, True, False])[1]
+
+
 def _weight_grad(x, dy, weight):
-    """dL/dweight of the k = 3 convolution: the split-K MFMA kernel, or the library's for shapes it does not take."""
-    if ops.conv3_wgrad_supported(x.shape[0], x.shape[1], dy.shape[1], x.shape[2]):
+    """dL/dweight of the k = 3, stride 1 convolution: the split-K MFMA kernel.  It stages whole sequences in LDS
+    (DR-SPAAM's cutouts: L <= 56); longer sequences (the Prototype's 57 ... 450 points) are cut into chunks with a
+    one-element halo: chunk c holds x[c Lc - 1 .. (c + 1) Lc] and dy[c Lc .. (c + 1) Lc) between two zeros, so that
+    sum_j dy_c[j] x_c[j + t - 1] over the chunks is the gradient of the whole sequence.  The library's kernel is
+    left for shapes neither form takes."""
+    S, ci, L = (int(v) for v in x.shape)
+    co = int(dy.shape[1])
+    if _wgrad_supported(S, ci, co, L, 3):
         return torch.ops.pof.conv3_wgrad(x, dy)
+    for lc in (62, 54, 46, 38, 30, 22, 14):
+        nc = -(-L // lc)
+        if _wgrad_supported(S * nc, ci, co, lc + 2, 3):
+            xp = torch.nn.functional.pad(x, (1, nc * lc - L + 1))
+            xc = xp.unfold(2, lc + 2, lc).permute(0, 2, 1, 3).reshape(S * nc, ci, lc + 2)
+            dyc = torch.nn.functional.pad(torch.nn.functional.pad(dy, (0, nc * lc - L)).reshape(S, co, nc, lc), (1, 1))
+            dyc = dyc.permute(0, 2, 1, 3).reshape(S * nc, co, lc + 2)
+            return torch.ops.pof.conv3_wgrad(xc.contiguous(), dyc.contiguous())
     return torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
                                                [False, True, False])[1]
 
@@ -256,6 +409,8 @@ _CONSTS = {}
 def _const(n, value, like):
     """A cached [n] float32 vector of ones / zeros on ``like``'s device (unit scale, zero shift of the plain
     convolution) -- not a fill kernel per call."""
+    if torch.compiler.is_compiling():
+        return torch.full((int(n),), float(value), dtype=torch.float32, device=like.device)
     key = (like.device, int(n), float(value))
     t = _CONSTS.get(key)
     if t is None:
@@ -377,6 +532,138 @@ def trunk_unit_train(x, conv, bn, negative_slope=0.1, pool=False, groups=1):
     rm, rv, momentum, eps = _bn_train_args(bn, groups, (x.shape[0], conv.out_channels, x.shape[2]))
     return TrunkUnitTrain.apply(x.contiguous(), conv.weight, conv.bias, bn.weight, bn.bias, rm, rv, momentum, eps,
                                 float(negative_slope), bool(pool), int(groups))
+
+
+class ConvUnitTrain(torch.autograd.Function):
+    """A unit of the Prototype flow network in training -- Conv1d(kernel 1 | 3, padding kernel // 2, stride 1 | 2) ->
+    BatchNorm1d(train) -> LeakyReLU -- as one autograd node on the HIP kernels (round 3).  Forward: the float32-MFMA
+    convolution ``pof_conv1d_bn_lrelu`` (unit scale, bias as shift, slope 1) and the fused BatchNorm tail.  Backward:
+    the tail's fused backward, then
+
+      kernel 3, stride 1   data gradient = the same convolution of dy with the taps reversed and the channel roles
+                           swapped; weight gradient = ``pof::conv3_wgrad``                        (as TrunkUnitTrain)
+      kernel 1             data gradient = the k = 1 convolution of dy with the transposed weight; weight gradient =
+                           ``pof::conv1_wgrad`` (the split-K kernel's one-tap form)
+      kernel 3, stride 2   y[l] = W0 x[2l-1] + W1 x[2l] + W2 x[2l+1], so with x_even[l] = x[2l], x_odd[l] = x[2l+1]:
+                           dx_even[l] = W1' dy[l]                 (a k = 1 convolution),
+                           dx_odd[l]  = W2' dy[l] + W0' dy[l+1]   (a k = 3 convolution with taps {0, W2', W0'}),
+                           dW1 = centre tap of wgrad(x_even, dy), (dW0, dW2) = taps 0, 1 of wgrad(x_odd, dy)
+                           -- every pass on the stride-1 kernels that exist, on de-interleaved copies.
+    Only x and the convolution output y are kept for the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, stride,
+                groups, rowmax=False):
+        co, ci, k = weight.shape
+        wt = weight.detach().permute(2, 1, 0).contiguous()
+        shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
+        y = torch.ops.pof.conv1d_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, stride, 1.0)
+        if rowmax:      # z [S, Co] = max over the positions, taken inside the tail's apply pass
+            z, mean, invstd = torch.ops.pof.bn_lrelu_rowmax(y, gamma, beta, running_mean, running_var, momentum, eps,
+                                                            negative_slope, groups)
+        else:
+            z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+                                                          negative_slope, False, groups)
+        ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd)
+        ctx.has_bias, ctx.negative_slope, ctx.stride, ctx.groups = bias is not None, negative_slope, stride, groups
+        ctx.rowmax = rowmax
+        return z
+
+    @staticmethod
+    def backward(ctx, g_z):
+        x, weight, y, gamma, beta, mean, invstd = ctx.saved_tensors
+        co, ci, k = weight.shape
+        stride = ctx.stride
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        if ctx.rowmax:
+            dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_rowmax_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
+                                                                           ctx.negative_slope, want_db, ctx.groups)
+        else:
+            dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
+                                                                         ctx.negative_slope, False, want_db, ctx.groups)
+        one, zero = _const(ci, 1.0, weight), _const(ci, 0.0, weight)
+        w = weight.detach()
+        lin, lo = x.shape[2], dy.shape[2]
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            if k == 3 and stride == 1:
+                dx = torch.ops.pof.conv1d_bn_lrelu(dy, w.flip(2).permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
+            elif k == 1:
+                dx = torch.ops.pof.conv1d_bn_lrelu(dy, w.permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
+            else:
+                dx = torch.empty_like(x)
+                w1 = w[:, :, 1:2].permute(2, 0, 1).contiguous()                                  # [1, Co, Ci]
+                dx[:, :, 0::2] = torch.ops.pof.conv1d_bn_lrelu(dy, w1, one, zero, 1, 1.0)     # even positions: lo of them
+                if lin > 1:
+                    wo = torch.stack((torch.zeros_like(w[:, :, 0]), w[:, :, 2], w[:, :, 0]), dim=0)   # taps dy[l-1], dy[l], dy[l+1]
+                    dxo = torch.ops.pof.conv1d_bn_lrelu(dy, wo.contiguous(), one, zero, 1, 1.0)
+                    dx[:, :, 1::2] = dxo[:, :, :lin // 2]
+        if ctx.needs_input_grad[1]:
+            if k == 3 and stride == 1:
+                dw = _weight_grad(x, dy, weight)
+            elif k == 1:
+                dw = _pointwise_weight_grad(x, dy, weight)
+            else:
+                xe = x[:, :, 0::2].contiguous()                                                  # [S, Ci, lo]
+                xo = x.new_zeros((x.shape[0], ci, lo))
+                xo[:, :, :lin // 2] = x[:, :, 1::2]
+                w3 = weight.new_empty((co, ci, 3))
+                ge, go = _weight_grad(xe, dy, w3), _weight_grad(xo, dy, w3)
+                dw = torch.stack((go[:, :, 0], ge[:, :, 1], go[:, :, 1]), dim=2)
+        return dx, dw, (db if want_db else None), dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def conv_unit_train(x, conv, bn, negative_slope, groups=1, rowmax=False):
+    """``leaky_relu(bn(conv(x)))`` for the modules of a Prototype unit in training mode (see ConvUnitTrain).  ``groups`` > 1:
+    x holds that many equally long batches one after the other (the two scans of a pair), each normalised with its own
+    batch statistics, the running statistics updated once per group in order -- what sending them through the unit
+    one by one does (prototype.py:70-80), in one launch per pass.  ``rowmax``: the result is the maximum over the
+    positions, [S, Co] (output length a power of two >= 4) -- the PointNet's last unit and its max over points."""
+    lo = (x.shape[2] + conv.stride[0] - 1) // conv.stride[0]
+    rm, rv, momentum, eps = _bn_train_args(bn, groups, (x.shape[0], conv.out_channels, lo))
+    return ConvUnitTrain.apply(x.contiguous().float(), conv.weight, conv.bias, bn.weight, bn.bias, rm, rv, momentum, eps,
+                               float(negative_slope), int(conv.stride[0]), int(groups), bool(rowmax))
+
+
+def conv_unit_train_supported(conv, length, channels_ok=True):
+    """Shapes ConvUnitTrain takes: kernel 3 (stride 1 | 2) or 1, and a BatchNorm tail within the fused kernels' range
+    (output length <= 256, Co x length a multiple of 4)."""
+    k, st = conv.kernel_size[0], conv.stride[0]
+    if not ((k == 3 and st in (1, 2)) or (k == 1 and st == 1)) or conv.padding[0] != k // 2:
+        return False
+    lo = (length + st - 1) // st
+    return lo <= 256 and (conv.out_channels * lo) % 4 == 0
+
+
+class Conv1dTrain(torch.autograd.Function):
+    """A plain Conv1d(kernel 1, stride 1) in training on the HIP kernels (the Prototype's point-wise head, whose 450-point
+    BatchNorm is outside the fused tail's range and stays a torch module): forward and data gradient are k = 1
+    convolutions on the float32-MFMA kernel, the weight gradient is ``pof::conv1_wgrad``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        co, ci, k = weight.shape
+        shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
+        y = torch.ops.pof.conv1d_bn_lrelu(x, weight.detach().permute(2, 1, 0).contiguous(), _const(co, 1.0, weight), shift,
+                                          1, 1.0)
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        co, ci, _ = weight.shape
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.ops.pof.conv1d_bn_lrelu(dy, weight.detach().permute(2, 0, 1).contiguous(), _const(ci, 1.0, weight),
+                                               _const(ci, 0.0, weight), 1, 1.0)
+        if ctx.needs_input_grad[1]:
+            dw = _pointwise_weight_grad(x, dy, weight)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy.sum(dim=(0, 2))
+        return dx, dw, db
 
 
 # ------------------------------------------------------------------------------------------------- A4

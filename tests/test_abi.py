@@ -108,3 +108,16 @@ def test_synth_is_deterministic():
     assert np.array_equal(a.scans, b.scans) and np.array_equal(a.odom1, b.odom1)
     o, r, c = a.det_csr()
     assert o[0] == 0 and o[-1] == len(r) == len(c)
+
+
+def test_wgrad_shape_predicate_mirrors_the_library(lib):
+    """torch_ops._wgrad_supported restates make_wgrad()'s shape test in Python (traceable by torch.compile); the library's
+    own answer -- a non-zero workspace size -- is the referee."""
+    from planar_optical_flow_amd import torch_ops
+    import itertools
+    lengths = list(range(1, 90)) + [96, 100, 112, 127, 128, 200, 255, 256, 257, 300, 450]
+    for L, (ci, co), S, k in itertools.product(lengths, ((1, 64), (64, 64), (64, 128), (128, 1024), (3, 5), (700, 65)),
+                                               (1, 7, 4096), (1, 3)):
+        want = lib.pof_conv1d_wgrad_workspace_bytes(S, ci, co, L, k) > 0
+        assert torch_ops._wgrad_supported(S, ci, co, L, k) == want, (S, ci, co, L, k)
+    assert not torch_ops._wgrad_supported(0, 4, 4, 8, 3) and not torch_ops._wgrad_supported(4, 4, 4, 8, 2)

@@ -3,8 +3,9 @@ written by tools/gen_golden.py::gen_gradients on the CPU of the build container)
 
   A9   Prototype._fusion                        prototype.py:118-156
   A10  _SpatialAttention.forward                dr_spaam.py:163-217
-  N2   one SpatialDROW / Prototype training step (loss + parameter gradients)
-                                                dr_spaam.py:41-121, 220-277; prototype.py:57-109
+  N2   one SpatialDROW / Prototype / box-head training step (loss + parameter gradients)
+                                                dr_spaam.py:41-121, 220-277; prototype.py:57-109;
+                                                src/model/box_regression.py:20-143
 
 Bar: 1e-4 of the gradient's scale (max |g| of the tensor) -- float32 sums in a different order on both sides.
 """
@@ -160,3 +161,48 @@ def test_prototype_training_step_equals_reference(golden):
         assert abs(float(gr.abs().sum()) - ab) <= 5e-3 * ab + 1e-7, (k, float(gr.abs().sum()), ab)
         assert abs(float(gr.sum()) - float(g["pt_gsum"][i])) <= 5e-3 * ab + 1e-7, (k,)
     close(dict(m.named_parameters())[str(g["pt_first_name"])].grad, g["pt_grad_first"], 2e-3, "d first conv")
+
+
+@pytest.mark.parametrize("hip", [True, False])
+def test_box_head_training_step_equals_reference(golden, hip):
+    """One training step of the box-regression head (BASELINE configs[3]; seeded weights = the reference's, dropout
+    off) against the reference's own autograd: PointNet units as ConvUnitTrain nodes on the HIP kernels (float32-MFMA
+    convolution forward / data gradient, one-tap split-K weight gradient, fused BatchNorm tail) and, for comparison, as
+    the torch modules.  Bar as for SpatialDROW: within 3x the reference's own float32 distance from its float64 run,
+    or 1e-4 of the tensor's scale."""
+    from src.model.get_model import get_model
+    g = golden("gradients")
+    torch.manual_seed(67)
+    m = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).to(DEV)
+    m.train()
+    m.backbone.hip_train = hip
+    pred = m(T(g["bh_in"]))
+    close(pred, g["bh_pred"], 2e-4, "prediction")
+    loss = m.loss_fn(pred, T(g["bh_tgt"]))
+    loss.backward()
+    np.testing.assert_allclose(float(loss.detach()), float(g["bh64_loss"]), rtol=2e-5)
+    params = dict(m.named_parameters())
+    names = list(g["bh_names"])
+    assert names == [k for k, p in m.named_parameters() if p.grad is not None]
+    top = float(g["bh64_gabs"].max())
+    for i, k in enumerate(names):
+        gr = params[k].grad.double()
+        ab64, ab32 = float(g["bh64_gabs"][i]), float(g["bh_gabs"][i])
+        s64, s32 = float(g["bh64_gsum"][i]), float(g["bh_gsum"][i])
+        tol_abs = 3.0 * abs(ab32 - ab64) + 1e-4 * ab64 + 1e-9 * top
+        tol_sum = 3.0 * abs(s32 - s64) + 1e-4 * ab64 + 1e-9 * top
+        assert abs(float(gr.abs().sum()) - ab64) <= tol_abs, (k, float(gr.abs().sum()), ab64, ab32)
+        assert abs(float(gr.sum()) - s64) <= tol_sum, (k, float(gr.sum()), s64, s32)
+    for key in g.files:
+        if not key.startswith("bh64_grad_"):
+            continue
+        name = key[len("bh64_grad_"):]
+        match = [k for k in names if k.replace(".", "_") == name]
+        assert len(match) == 1, name
+        want64, ref32 = g[key], g["bh_grad_" + name]
+        got = params[match[0]].grad.detach().cpu().numpy().astype(np.float64)
+        scale = float(np.abs(want64).max())
+        err = float(np.abs(got - want64).max())
+        ref_err = float(np.abs(ref32.astype(np.float64) - want64).max())
+        assert err <= 3.0 * ref_err + 1e-4 * scale + 1e-12 * top, (match[0], err, ref_err, scale)
+    close(dict(m.named_buffers())["backbone.conv4.1.running_var"], g["bh_run_var_c4"], 1e-4, "running var")

@@ -7,7 +7,8 @@ import torch
 from planar_optical_flow_amd import torch_ops  # noqa: F401  (registers torch.ops.pof.*)
 
 OPS = ("band_correlation", "band_correlation_backward", "spatial_attention", "spatial_attention_backward", "cutout",
-       "conv3_bn_lrelu", "rotate_flow", "bn_lrelu_pool", "bn_lrelu_pool_backward", "conv3_wgrad")
+       "conv3_bn_lrelu", "rotate_flow", "bn_lrelu_pool", "bn_lrelu_pool_backward", "conv3_wgrad", "conv1_wgrad",
+       "conv1d_bn_lrelu", "bn_lrelu_rowmax", "bn_lrelu_rowmax_backward", "linear_bias")
 
 
 def test_ops_are_registered_with_schemas():
@@ -31,6 +32,14 @@ def test_training_ops_fake_kernels():
         assert dy.shape == y.shape and tuple(dg.shape) == tuple(db.shape) == tuple(ds.shape) == (64,)
         dw = torch.ops.pof.conv3_wgrad(torch.empty(90, 32, 48, device="cuda"), y)
         assert tuple(dw.shape) == (64, 32, 3)
+        assert tuple(torch.ops.pof.conv1_wgrad(torch.empty(90, 32, 48, device="cuda"), y).shape) == (64, 32, 1)
+        wt = torch.empty(3, 64, 128, device="cuda")
+        assert tuple(torch.ops.pof.conv1d_bn_lrelu(y, wt, g, g, 2, 0.1).shape) == (90, 128, 24)
+        y64 = torch.empty(90, 64, 64, device="cuda")
+        zm, mu2, _ = torch.ops.pof.bn_lrelu_rowmax(y64, g, g, None, None, 0.1, 1e-5, 0.1, 2)
+        assert tuple(zm.shape) == (90, 64) and tuple(mu2.shape) == (128,)
+        dy2, _, _, ds2 = torch.ops.pof.bn_lrelu_rowmax_backward(y64, zm, g, g, mu2, mu2, 0.1, False, 2)
+        assert dy2.shape == y64.shape and tuple(ds2.shape) == (0,)
 
 
 def test_fake_kernels_give_the_output_shapes_without_running_anything():
@@ -154,6 +163,89 @@ def test_bn_lrelu_pool_matches_torch_modules(S, C, L, pool):
     assert float((y.grad.double() - y64.grad).abs().max()) <= 2e-5 * max(scale, 1.0)
     for got, want in ((bn.weight.grad, ref_bn.weight.grad), (bn.bias.grad, ref_bn.bias.grad)):
         assert float((got.double() - want).abs().max()) <= 1e-5 * max(float(want.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,C,L,groups", [(256, 1024, 64, 1), (37, 24, 4, 1), (12, 16, 256, 2), (9, 5, 8, 1), (40, 128, 32, 1)])
+def test_bn_lrelu_rowmax_matches_torch(S, C, L, groups):
+    """pool mode 2 -- max over the whole row inside the apply pass, gradient routed to the row's first maximum -- against
+    BatchNorm1d(train) -> leaky_relu -> torch.max(dim=2) in float64 (forward, running statistics, all gradients)."""
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + C + L)
+    y = torch.randn(S, C, L, device="cuda", generator=g) * 1.5 + 0.3
+    gam = torch.rand(C, device="cuda", generator=g) + 0.5
+    bet = torch.randn(C, device="cuda", generator=g) * 0.2
+    dz = torch.randn(S, C, device="cuda", generator=g)
+    rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+    z, mu, istd = ops.bn_lrelu_pool_forward(y, gam, bet, rm, rv, pool=2, groups=groups)
+    dy, dgam, dbet, dsum = ops.bn_lrelu_pool_backward(y, dz, gam, bet, mu, istd, pool=2, bias_grad=True, groups=groups)
+    assert z.shape == (S, C)
+    y64 = y.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rm64, rv64 = torch.zeros(C, device="cuda", dtype=torch.float64), torch.ones(C, device="cuda", dtype=torch.float64)
+    outs = []
+    for part in y64.chunk(groups, dim=0):
+        u = torch.nn.functional.batch_norm(part, rm64, rv64, g64, b64, True, 0.1, 1e-5)
+        outs.append(torch.max(torch.nn.functional.leaky_relu(u, 0.1), 2)[0])
+    z64 = torch.cat(outs, dim=0)
+    z64.backward(dz.double())
+    assert float((z.double() - z64).abs().max()) <= 2e-5 * float(z64.abs().max())
+    for got, want in ((dy, y64.grad), (dgam, g64.grad), (dbet, b64.grad)):
+        assert float((got.double() - want).abs().max()) <= 1e-4 * max(float(want.abs().max()), 1.0)
+    assert float(dsum.abs().max()) <= 1e-3 * max(float(dz.abs().sum(dim=0).max()), 1.0)     # zero in exact arithmetic
+    assert torch.allclose(rm.double(), rm64, rtol=1e-5, atol=1e-6) and torch.allclose(rv.double(), rv64, rtol=1e-5, atol=1e-6)
+    # ties: the FIRST maximum of a row takes the whole gradient
+    yt = torch.zeros(2, 4, 8, device="cuda")
+    yt[:, :, 3] = 1.0
+    yt[:, :, 6] = 1.0
+    yt[0] *= 2.0
+    zt, mt, it = ops.bn_lrelu_pool_forward(yt, torch.ones(4, device="cuda"), torch.zeros(4, device="cuda"), pool=2)
+    dyt, _, dbt = ops.bn_lrelu_pool_backward(yt, torch.ones(2, 4, device="cuda"), torch.ones(4, device="cuda"),
+                                             torch.zeros(4, device="cuda"), mt, it, pool=2)
+    assert torch.equal(dbt, torch.full((4,), 2.0, device="cuda"))
+    assert not ops.bn_lrelu_pool_supported(4, 4, 12, pool=2) and ops.bn_lrelu_pool_supported(4, 4, 16, pool=2)
+    with pytest.raises(ValueError):
+        ops.bn_lrelu_pool_forward(torch.zeros(4, 4, 12, device="cuda"), torch.ones(4, device="cuda"),
+                                  torch.zeros(4, device="cuda"), pool=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,N", [(256, 1024, 512), (256, 512, 256), (256, 256, 3), (1, 8, 1), (37, 100, 45), (300, 12, 70),
+                                   (1024, 512, 256), (5, 4, 33)])
+def test_linear_bias_equals_torch_linear(B, K, N):
+    """pof::linear_bias (the box head's dense layers, src/model/box_regression.py:26-45) against torch's float64 Linear;
+    exact on small integers; gradients through the registered autograd formula against F.linear's."""
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B + K + N)
+    x = torch.randn(B, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g)
+    b = torch.randn(N, device="cuda", generator=g)
+    want = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    got = ops.linear_bias(x, w, b)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * K ** 0.5 * max(float(want.abs().max()), 1.0)
+    assert torch.equal(got, ops.linear_bias(x, w, b))                      # deterministic
+    xi = torch.randint(-4, 5, (B, K), device="cuda", generator=g).float()
+    wi = torch.randint(-4, 5, (N, K), device="cuda", generator=g).float()
+    assert torch.equal(ops.linear_bias(xi, wi).double(), xi.double() @ wi.double().t())     # no bias; exact sums
+    xa, wa, ba = (t.clone().requires_grad_(True) for t in (x, w, b))
+    xr, wr, br = (t.clone().requires_grad_(True) for t in (x, w, b))
+    up = torch.randn(B, N, device="cuda", generator=g)
+    torch.ops.pof.linear_bias(xa, wa, ba).backward(up)
+    torch.nn.functional.linear(xr, wr, br).backward(up)
+    for a_, r_ in ((xa, xr), (wa, wr), (ba, br)):
+        assert float((a_.grad - r_.grad).abs().max()) <= 1e-4 * max(float(r_.grad.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+def test_linear_bias_rejects_what_it_cannot_take():
+    from planar_optical_flow_amd import ops
+    with pytest.raises(ValueError):
+        ops.linear_bias(torch.zeros(4, 6, device="cuda"), torch.zeros(3, 6, device="cuda"))      # K % 4
+    with pytest.raises(ValueError):
+        ops.linear_bias(torch.zeros(4, 8, device="cuda"), torch.zeros(3, 12, device="cuda"))
+    with pytest.raises((ValueError, RuntimeError, TypeError)):
+        ops.linear_bias(torch.zeros(4, 8), torch.zeros(3, 8))                                        # CPU tensors: no fallback
+    assert ops.linear_bias(torch.zeros(0, 8, device="cuda"), torch.zeros(3, 8, device="cuda")).shape == (0, 3)
 
 
 @pytest.mark.gpu
@@ -284,6 +376,45 @@ def test_conv3_wgrad_exact_on_integer_data_and_deterministic():
     assert torch.equal(dw, ops.conv3_wgrad(x, dy))
     xr, dyr = torch.randn_like(x), torch.randn_like(dy)
     assert torch.equal(ops.conv3_wgrad(xr, dyr), ops.conv3_wgrad(xr, dyr))   # no atomics: bit-stable
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Ci,Co,L", [(256, 128, 1024, 64), (64, 3, 64, 64), (31, 64, 128, 64), (17, 70, 33, 31),
+                                        (5, 64, 64, 1), (9, 128, 2, 60), (33, 64, 64, 48)])
+def test_conv1_wgrad_matches_autograd_and_is_exact_on_integers(S, Ci, Co, L):
+    """One-tap form of the split-K kernel (the PointNet's / the Prototype head's point-wise convolutions) against
+    torch's float64 weight gradient; on small integers every sum is exact in float32."""
+    from planar_optical_flow_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(S + 3 * Ci + 5 * Co + L)
+    for integers in (False, True):
+        if integers:
+            x = torch.randint(-3, 4, (S, Ci, L), device="cuda", generator=g).float()
+            dy = torch.randint(-3, 4, (S, Co, L), device="cuda", generator=g).float()
+        else:
+            x = torch.randn(S, Ci, L, device="cuda", generator=g)
+            dy = torch.randn(S, Co, L, device="cuda", generator=g)
+        want = torch.einsum("sol,sil->oi", dy.double(), x.double()).unsqueeze(-1)
+        assert ops.conv3_wgrad_supported(S, Ci, Co, L, 1)
+        dw = ops.conv3_wgrad(x, dy, kernel_size=1)
+        assert dw.shape == (Co, Ci, 1)
+        if integers:
+            assert torch.equal(dw.double(), want)
+        else:
+            assert float((dw.double() - want).abs().max()) <= 2e-5 * max(float(want.abs().max()), 1.0)
+        assert torch.equal(dw, ops.conv3_wgrad(x, dy, kernel_size=1))
+
+
+@pytest.mark.gpu
+def test_pointwise_weight_grad_chunks_long_rows():
+    """Rows longer than the kernel's LDS stage (the Prototype head's 450 points) are cut into chunks."""
+    from planar_optical_flow_amd import torch_ops, ops
+    g = torch.Generator(device="cuda").manual_seed(11)
+    x = torch.randn(6, 64, 450, device="cuda", generator=g)
+    dy = torch.randn(6, 2, 450, device="cuda", generator=g)
+    assert not ops.conv3_wgrad_supported(6, 64, 2, 450, 1)
+    dw = torch_ops._pointwise_weight_grad(x, dy, torch.empty(2, 64, 1, device="cuda"))
+    want = torch.einsum("sol,sil->oi", dy.double(), x.double()).unsqueeze(-1)
+    assert float((dw.double() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
 @pytest.mark.gpu
@@ -430,3 +561,73 @@ def test_fused_tail_refuses_one_value_per_channel_like_torch():
         bn(y)
     with pytest.raises(ValueError, match="Expected more than 1 value per channel"):
         torch_ops.bn_lrelu_pool_train(y, bn, 0.1, False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,Ci,Co,L,K,stride,groups", [(6, 1, 64, 450, 3, 2, 2), (4, 64, 128, 225, 3, 2, 2), (4, 128, 256, 113, 3, 2, 1),
+                                                        (3, 139, 128, 113, 3, 1, 1), (2, 192, 128, 225, 3, 1, 1), (5, 16, 8, 64, 1, 1, 1),
+                                                        (4, 6, 12, 7, 3, 2, 2), (3, 5, 16, 9, 3, 1, 1)])
+def test_conv_unit_train_equals_modules(S, Ci, Co, L, K, stride, groups):
+    """torch_ops.ConvUnitTrain -- Conv1d(k = 1 | 3, stride 1 | 2) -> BatchNorm1d(train) -> LeakyReLU(0.01) as one autograd node
+    on the HIP kernels (stride-2 gradients through the even / odd decomposition, weight gradients of long sequences
+    through halo chunks) -- against the torch modules in float64: output, running statistics and all five gradients
+    to 1e-4 of each tensor's scale; `groups` batches normalised separately like separate module calls."""
+    import torch.nn as nn
+    from planar_optical_flow_amd import torch_ops
+    torch.manual_seed(S * 100 + Ci + K + stride)
+    conv = nn.Conv1d(Ci, Co, K, stride=stride, padding=K // 2).cuda()
+    bn = nn.BatchNorm1d(Co).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    conv64, bn64 = nn.Conv1d(Ci, Co, K, stride=stride, padding=K // 2).cuda().double(), nn.BatchNorm1d(Co).cuda().double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    bn64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bn.state_dict().items()})
+    x = torch.randn(S, Ci, L, device="cuda", requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    z = torch_ops.conv_unit_train(x, conv, bn, 0.01, groups=groups)
+    z64 = torch.cat([torch.nn.functional.leaky_relu(bn64(conv64(part)), 0.01) for part in x64.chunk(groups, dim=0)], dim=0)
+    up = torch.randn_like(z)
+    z.backward(up)
+    z64.backward(up.double())
+
+    def close(a, b, what, rel=1e-4):
+        scale = float(b.abs().max()) or 1.0
+        err = float((a.double() - b).abs().max())
+        assert err <= rel * scale, (what, err, scale)
+    close(z, z64, "output")
+    close(bn.running_mean, bn64.running_mean, "running mean")
+    close(bn.running_var, bn64.running_var, "running var")
+    assert int(bn.num_batches_tracked) == groups
+    close(x.grad, x64.grad, "d x")
+    close(conv.weight.grad, conv64.weight.grad, "d weight")
+    close(bn.weight.grad, bn64.weight.grad, "d gamma")
+    close(bn.bias.grad, bn64.bias.grad, "d beta")
+    # the conv bias in front of a BatchNorm has a zero gradient: round-off on both sides, on the scale of d gamma
+    assert float(conv.bias.grad.abs().max()) <= 1e-4 * float(bn64.weight.grad.abs().max()) + 1e-6
+
+
+@pytest.mark.gpu
+def test_prototype_hip_training_equals_module_training():
+    """Prototype.forward in training mode on the device: every unit through ConvUnitTrain / Conv1dTrain (hip_train) against
+    the same model through the torch modules: prediction, loss, every gradient (1e-3 of the largest gradient) and every
+    BatchNorm's running statistics and batch counter."""
+    import copy
+    from planar_optical_flow_amd.src.depracted.model.prototype import Prototype, flow_loss
+    torch.manual_seed(11)
+    a = Prototype(in_channel=1, max_displacement=5).cuda().train()
+    b = copy.deepcopy(a)
+    b.hip_train = False
+    s1, s2 = torch.randn(6, 450, 1, device="cuda"), torch.randn(6, 450, 1, device="cuda")
+    tgt = torch.randn(6, 450, 2, device="cuda") * 0.2
+    pa, pb = a(s1, s2), b(s1, s2)
+    assert float((pa - pb).abs().max()) <= 1e-3 * float(pb.abs().max())
+    la, lb = flow_loss(pa, tgt)[0], flow_loss(pb, tgt)[0]
+    la.backward()
+    lb.backward()
+    assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(lb))
+    top = max(float(q.grad.abs().max()) for q in b.parameters())
+    for (n, p), (_, q) in zip(a.named_parameters(), b.named_parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 1e-3 * top, n
+    for (n, u), (_, v) in zip(a.named_buffers(), b.named_buffers()):
+        assert float((u.double() - v.double()).abs().max()) <= 1e-4 * max(1.0, float(v.double().abs().max())), n

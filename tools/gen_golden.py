@@ -293,6 +293,35 @@ def gen_gradients():
     first = next(iter(pref.named_parameters()))
     g["pt_grad_first"] = first[1].grad.numpy()
     g["pt_first_name"] = np.array(first[0])
+    # ---- N2 / configs[3]: one box-head training step (model_fn's loss; dropout off so the step is deterministic),
+    #      float32 as the reference runs plus the float64 yardstick                 box_regression.py:20-143
+    from src.model.get_model import get_model as ref_get_model
+    cfg_b = {"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}
+    torch.manual_seed(67)
+    bref = ref_get_model(cfg_b)
+    bref.train()
+    b64 = ref_get_model(cfg_b).double()
+    b64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in bref.state_dict().items()})
+    b64.train()
+    bx, bt = torch.randn(48, 64, 3), torch.randn(48, 3)
+    bp = bref(bx)
+    bl = bref.loss_fn(bp, bt)
+    bl.backward()
+    bl64 = b64.loss_fn(b64(bx.double()), bt.double())
+    bl64.backward()
+    used = [(k, p) for k, p in bref.named_parameters() if p.grad is not None]
+    g["bh_in"], g["bh_tgt"], g["bh_pred"], g["bh_loss"] = bx.numpy(), bt.numpy(), bp.detach().numpy(), np.array(float(bl.detach()))
+    g["bh_names"] = np.array([k for k, _ in used])
+    g["bh_gsum"] = np.array([float(p.grad.double().sum()) for _, p in used])
+    g["bh_gabs"] = np.array([float(p.grad.double().abs().sum()) for _, p in used])
+    p64 = dict(b64.named_parameters())
+    g["bh64_loss"] = np.array(float(bl64.detach()))
+    g["bh64_gsum"] = np.array([float(p64[k].grad.sum()) for k, _ in used])
+    g["bh64_gabs"] = np.array([float(p64[k].grad.abs().sum()) for k, _ in used])
+    for k in ("backbone.conv1.0.weight", "backbone.conv3.0.weight", "backbone.conv4.1.weight", "fc3.weight"):
+        g["bh_grad_" + k.replace(".", "_")] = dict(used)[k].grad.numpy()
+        g["bh64_grad_" + k.replace(".", "_")] = p64[k].grad.numpy()
+    g["bh_run_var_c4"] = dict(bref.named_buffers())["backbone.conv4.1.running_var"].numpy()
     np.savez_compressed(os.path.join(OUT, "gradients.npz"), **g)
 
 
