@@ -486,6 +486,16 @@ int pof_linear_bias(const float *x, const float *w, const float *bias, int B, in
                     pof_stream_t stream);
 
 /* ----------------------------------------------------------------------
+ * configs[3] box-regression loss                   src/model/box_regression.py:52-67 (regression_loss2)
+ * pred, target [B][T] float32, T = 3 (dims, dims, orientation) or 5 (z, 3 dims, orientation):
+ * loss[0] = mean_b sum_j c_j |pred - target|, c_j = 1 except c_{T-1} = alpha; dpred [B][T] (or
+ * NULL) = d loss / d pred = c_j sign(pred - target) / B.  One launch instead of the ~27 the
+ * composed form takes forward and backward.
+ * ---------------------------------------------------------------------- */
+int pof_regression_loss2(const float *pred, const float *target, long long B, int T, double alpha, float *loss,
+                         float *dpred, pof_stream_t stream);
+
+/* ----------------------------------------------------------------------
  * N3 BoxRegressor input preparation, batched     box_regressor.py:43-75, :94-105
  *                                                src/data_handle/jrdb_handle.py:178-256
  * points [Np][D] float64 (D = 2 or 3), centers [S][D], oris [S] -> per detection the

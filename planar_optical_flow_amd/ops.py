@@ -523,6 +523,20 @@ def conv3_wgrad(x, dy, kernel_size=3):
     return dw
 
 
+def regression_loss2(pred, target, alpha=0.5, with_grad=True):
+    """configs[3] loss: pred, target [B,3|5] f32 -> (loss [] f32, d loss / d pred [B,T] f32 or None) in one launch."""
+    pred = _dev(pred, torch.float32, "pred")
+    target = _dev(target, torch.float32, "target")
+    if pred.dim() != 2 or tuple(target.shape) != tuple(pred.shape) or pred.shape[1] not in (3, 5) or pred.shape[0] < 1:
+        raise ValueError("pred and target must be [B, 3] or [B, 5] with B >= 1")
+    loss = torch.empty((), dtype=torch.float32, device=pred.device)
+    dpred = torch.empty_like(pred) if with_grad else None
+    with torch.cuda.device(pred.device):
+        _lib.call("pof_regression_loss2", _ptr(pred), _ptr(target), pred.shape[0], pred.shape[1], float(alpha), _ptr(loss),
+                  _ptr(dpred), _stream())
+    return loss, dpred
+
+
 def linear_bias(x, weight, bias=None, out=None):
     """configs[3] dense layers: x [B,K] f32, weight [N,K] f32 (torch.nn.Linear's), bias [N] f32 or None -> x @ weight.T
     + bias [B,N] on the small-batch MFMA kernel (K a multiple of 4)."""

@@ -31,7 +31,12 @@ def _dense(cin, cout, batch_norm=True, nonlinearity=True):
 
 def regression_loss2(pred, target, alpha=0.5):
     """:52-67.  L1 on the box dimensions + alpha * L1 on the orientation residual
-    (+ L1 on z for the 5-target 3-D variant)."""
+    (+ L1 on z for the 5-target 3-D variant).  On the device: loss and its gradient in one launch
+    (``pof::regression_loss2``) instead of a dozen element-wise / reduction kernels each way."""
+    if pred.is_cuda and pred.dim() == 2 and pred.shape[1] in (3, 5) and pred.shape[0] > 0 \
+            and pred.dtype == torch.float32 and tuple(target.shape) == tuple(pred.shape) and not target.requires_grad:
+        from planar_optical_flow_amd import torch_ops  # noqa: F401  (registers torch.ops.pof.*)
+        return torch.ops.pof.regression_loss2(pred, target.float(), float(alpha))[0]
     ori = torch.mean(torch.abs(pred[..., -1] - target[..., -1]))
     if pred.shape[1] == 5:
         z = torch.mean(torch.abs(pred[..., 0] - target[..., 0]))

@@ -21,6 +21,7 @@ without running a kernel, and an ``opcheck``-able schema.  Device kernels only: 
         -> (Tensor z, Tensor mean, Tensor invstd)
     pof::conv3_wgrad(Tensor x, Tensor dy) -> Tensor
     pof::linear_bias(Tensor x, Tensor weight, Tensor? bias) -> Tensor
+    pof::regression_loss2(Tensor pred, Tensor target, float alpha) -> (Tensor loss, Tensor dpred)
     pof::bn_lrelu_pool_backward(Tensor y, Tensor dz, Tensor gamma, Tensor beta, Tensor mean, Tensor invstd,
         float negative_slope, bool pool, bool bias_grad, int groups=1) -> (Tensor, Tensor, Tensor, Tensor)
 """
@@ -191,6 +192,29 @@ def _linear_backward(ctx, g):
 
 
 linear_bias.register_autograd(_linear_backward, setup_context=_linear_setup)
+
+
+@torch.library.custom_op("pof::regression_loss2", mutates_args=(), device_types="cuda")
+def regression_loss2(pred: torch.Tensor, target: torch.Tensor, alpha: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    loss, dpred = ops.regression_loss2(pred.contiguous(), target.contiguous(), alpha)
+    return loss, dpred
+
+
+@regression_loss2.register_fake
+def _(pred, target, alpha):
+    return pred.new_empty(()), torch.empty_like(pred)
+
+
+def _loss2_setup(ctx, inputs, output):
+    ctx.save_for_backward(output[1])
+
+
+def _loss2_backward(ctx, g_loss, g_dpred):
+    (dpred,) = ctx.saved_tensors
+    return dpred * g_loss, None, None
+
+
+regression_loss2.register_autograd(_loss2_backward, setup_context=_loss2_setup)
 
 
 def linear_small(x, linear):

@@ -8,7 +8,8 @@ from planar_optical_flow_amd import torch_ops  # noqa: F401  (registers torch.op
 
 OPS = ("band_correlation", "band_correlation_backward", "spatial_attention", "spatial_attention_backward", "cutout",
        "conv3_bn_lrelu", "rotate_flow", "bn_lrelu_pool", "bn_lrelu_pool_backward", "conv3_wgrad", "conv1_wgrad",
-       "conv1d_bn_lrelu", "bn_lrelu_rowmax", "bn_lrelu_rowmax_backward", "linear_bias")
+       "conv1d_bn_lrelu", "bn_lrelu_rowmax", "bn_lrelu_rowmax_backward", "linear_bias",
+       "regression_loss2")
 
 
 def test_ops_are_registered_with_schemas():
@@ -234,6 +235,32 @@ def test_linear_bias_equals_torch_linear(B, K, N):
     torch.nn.functional.linear(xr, wr, br).backward(up)
     for a_, r_ in ((xa, xr), (wa, wr), (ba, br)):
         assert float((a_.grad - r_.grad).abs().max()) <= 1e-4 * max(float(r_.grad.abs().max()), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T", [(256, 3), (48, 5), (1, 3), (3000, 5)])
+def test_regression_loss2_equals_the_composed_form(B, T):
+    """pof::regression_loss2 (src/model/box_regression.py:52-67) -- loss and gradient in one launch -- against the
+    composed torch form in float64, and through the model's own loss function."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd"))
+    from src.model.box_regression import regression_loss2
+    g = torch.Generator(device="cuda").manual_seed(B + T)
+    pred = torch.randn(B, T, device="cuda", generator=g)
+    tgt = torch.randn(B, T, device="cuda", generator=g)
+    pred[0, 0] = tgt[0, 0]                                       # |x| at 0: gradient 0 (torch.abs' convention)
+    p64 = pred.double().cpu().requires_grad_(True)
+    want = regression_loss2(p64, tgt.double().cpu(), alpha=0.3)             # CPU float64: the composed reference form
+    want.backward()
+    p = pred.clone().requires_grad_(True)
+    got = regression_loss2(p, tgt, alpha=0.3)
+    assert got.dim() == 0 and abs(float(got) - float(want)) <= 2e-7 * abs(float(want))
+    (got * 2.0).backward()
+    assert float((p.grad.double().cpu() - 2.0 * p64.grad).abs().max()) <= 1e-7 * float(p64.grad.abs().max()) * 2.0 + 1e-12
+    assert float(p.grad[0, 0]) == 0.0
+    torch.library.opcheck(torch.ops.pof.regression_loss2, (pred.clone().requires_grad_(True), tgt, 0.5),
+                          test_utils=("test_schema", "test_faketensor", "test_autograd_registration"))
+    assert regression_loss2(torch.zeros(4, 4, device="cuda"), torch.zeros(4, 4, device="cuda")) is None   # as the reference
 
 
 @pytest.mark.gpu
