@@ -165,6 +165,12 @@ __device__ __forceinline__ float finish_value(const CutArgs &a, double ct, doubl
 //               the index range its windows touch and stages only that span of every
 //               row (falls back to L2 gathers when even the span does not fit);
 //            0: gathers straight from global memory
+//            3 (round 3; VMODE 1 only): as 1, but the rows are staged as float32 PAIRS {v[i] / depth, (v[i+1] - v[i]) /
+//               depth}, so that a lerp tap is one 8-byte LDS read and the float32 subtraction and the scaling by
+//               1/depth (a power of two: it commutes with every rounding of the sequence) leave the per-sample path:
+//               11 -> 8 vector instructions per tap.  Worth 7 % where one index serves T scans (fixed = False);
+//               nothing at fixed = True, which is bound by the float64-rate instructions (a float64-pair form that
+//               also drops the two conversions needs 2x the LDS and measured slower: profiles/r3_cutout_experiments.txt)
 //   P4       > 0: P/8 as a compile-time constant (7, 6, 4 for P = 56, 48, 32): the lane ->
 //            (window, k-group) split is a multiply and every lane produces 8 consecutive
 //            cutout samples (two float4 stores), which amortises the per-window LDS reads;
@@ -177,8 +183,11 @@ __device__ __forceinline__ float finish_value(const CutArgs &a, double ct, doubl
 //               centre arithmetic runs in float32 (|error| <= 1e-5 in the normalised output;
 //               saturated samples are exactly +-1).  Opt-in (value_mode = 1).
 //   DBG      also write the inds_ct_low debug tensor (tests only)
+#ifndef POF_CUTOUT_MINWG
+#define POF_CUTOUT_MINWG 4      // workgroups per CU the register allocation is held to (tools: experimental builds)
+#endif
 template <int LDSMODE, int P4, int VMODE, bool DBG>
-__global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
+__global__ __launch_bounds__(kThreads, POF_CUTOUT_MINWG) void cutout_kernel(CutArgs a)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     const int cap = a.fixed ? a.tile * a.T : a.tile;
@@ -193,7 +202,11 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     const double phi0 = a.tab[0], dphi = a.tab[1] - a.tab[0], rdphi = 1.0 / dphi;
     const int s_area = (a.area_mode && a.s_area) ? a.s_area[b] : 0;
     const int PA = s_area * P;
-    constexpr bool LDSROWS = LDSMODE == 1;
+    constexpr bool LDSROWS = LDSMODE == 1 || LDSMODE == 3;
+    constexpr int PAIR = LDSMODE == 3 ? 1 : 0;
+    static_assert(PAIR == 0 || (VMODE == 1 && !DBG), "pair rows: centred output with a power-of-two depth only");
+    using PairT = float2;
+    PairT *s_pair = reinterpret_cast<PairT *>(s_rows);
     __shared__ int s_span_lo, s_span_hi, s_acount;
     // k as float64, k < 64: phase B reads its eight k values per lane from here (two per 16-byte LDS read) instead
     // of forming them with eight float64 additions
@@ -292,7 +305,42 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         wt.step_a[p] = step_a;
         if (isarea) wt.alist[atomicAdd(&s_acount, 1)] = p;
     }
-    if (LDSROWS) {
+    if (PAIR) {
+        // {v, next - v} scaled by 1/depth; "next" of a row's last beam is the next row's first (0 behind the last
+        // row) -- the word the two-tap read of the plain layout finds there; it only ever meets ratio 0
+        const float sc = a.rdepth_f32;
+        auto mk = [&](float v, float nx) {
+            PairT r;
+            r.x = sc * v;
+            r.y = sc * (nx - v);
+            return r;
+        };
+        if (vec_stage) {
+            // the element behind a lane's two is the next lane's first: a shuffle inside the wave, a word through LDS
+            // at the wave's end (lane 0 of every wave publishes its first elements)
+            __shared__ float s_first[kWaves][kMaxStage + 1];
+            const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+            if (ln == 0) {
+#pragma unroll
+                for (int v = 0; v < kMaxStage; ++v) s_first[wv][v] = stage[v].x;
+                s_first[wv][kMaxStage] = 0.0f;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int v = 0; v < kMaxStage; ++v) {
+                const int e = threadIdx.x + v * kThreads;
+                float nx = __shfl_down(stage[v].x, 1, 64);
+                if (ln == 63) nx = wv + 1 < kWaves ? s_first[wv + 1][v] : s_first[0][v + 1];
+                if (2 * e + 2 >= T * N) nx = 0.0f;
+                if (e < nvec) {
+                    s_pair[2 * e] = mk(stage[v].x, stage[v].y);
+                    s_pair[2 * e + 1] = mk(stage[v].y, nx);
+                }
+            }
+        } else {
+            for (int e = threadIdx.x; e < T * N; e += kThreads) s_pair[e] = mk(smp[e], e + 1 < T * N ? smp[e + 1] : 0.0f);
+        }
+    } else if (LDSROWS) {
         if (threadIdx.x == 0) s_rows[T * N] = 0.0f;      // pad word behind the last row (second lerp tap)
         if (vec_stage) {
 #pragma unroll
@@ -322,7 +370,9 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         __syncthreads();
     }
     // row source as a compile-time tag: a pointer selected at run time would turn every tap into a flat_load
+    // (pair rows: the value comes back scaled by 1/depth -- sums, the mean and the centring commute with it)
     auto fetch_from = [&](auto lds_tag, int off) -> float {
+        if (PAIR) return (float)s_pair[off].x;
         if (decltype(lds_tag)::value) return s_rows[off];
         return smp[off];
     };
@@ -345,7 +395,7 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         // test, no index clamp, no padding select
         constexpr bool FULL = decltype(full_tag)::value;
         const double a0 = wt.a0[p], step = wt.step[p];
-        const double dd = wt.dd[p];
+        const double dd = PAIR ? wt.dd[p] * a.rdepth : wt.dd[p];       // pair rows: everything in units of the depth
         const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
         const int kr = FULL ? 0 : wt.krange[p];
@@ -412,7 +462,11 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
 #pragma unroll
             for (int u = 0; u < KV; ++u) {
                 float y;
-                {
+                if (PAIR) {
+                    const PairT tv = s_pair[roff + lo[u]];
+                    const double ct = (double)tv.x + ratio[u] * (double)tv.y;
+                    y = (float)(ct - dd);
+                } else {
                     float vlo, vhi;
                     if (LDSMODE == 1) {
                         // both taps with one LDS access (adjacent words).  At lo = N-1 the second tap is the
@@ -489,7 +543,7 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     auto area_outputs = [&](auto lds_tag, const int p, const int k_begin, const int k_count) {
         auto fetch = [&](int off) -> float { return fetch_from(lds_tag, off); };
         const double a0 = wt.a0[p], step_a = wt.step_a[p];
-        const double dd = wt.dd[p];
+        const double dd = PAIR ? wt.dd[p] * a.rdepth : wt.dd[p];
         const float ylo = wt.ylo[p], yhi = wt.yhi[p], ypad = wt.ypad[p];
         const int out_off = wt.out_off[p], row_off = wt.row_off[p];
         const int kr = wt.krange[p];
@@ -562,7 +616,9 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
                         mean_a = __fdiv_rn(acc, area_fs);
                     }
                     float y;
-                    if (VMODE == 2) {
+                    if (PAIR) {
+                        y = (float)((double)mean_a - dd);
+                    } else if (VMODE == 2) {
                         const float df = (float)dd;
                         y = a.centered ? (a.depth_pow2 ? (mean_a - df) * a.rdepth_f32 : __fdiv_rn(mean_a - df, a.depth_f32))
                                        : mean_a;
@@ -605,7 +661,7 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
         const bool work = act && !wt.isarea[p];
         const int kr = wt.krange[p];
         const bool full = (kr & 0xffff) <= k0 && k0 + KV - 1 <= (kr >> 16);
-        if (LDSMODE == 1 || (LDSMODE == 2 && span_lds)) {
+        if (LDSROWS || (LDSMODE == 2 && span_lds)) {
             if (__all(full || !work)) {
                 if (work) group(std::true_type{}, std::true_type{}, p, k0);
             } else {
@@ -621,7 +677,7 @@ __global__ __launch_bounds__(kThreads, 4) void cutout_kernel(CutArgs a)
     // are few (0.5-degree scans: the near field only) the list phase A compacted is spread over the lanes, KV
     // outputs each, so that a handful of windows does not serialise on a handful of lanes.
     const int n_area = s_area > 0 ? s_acount : 0;
-    const bool lds_rows = LDSMODE == 1 || (LDSMODE == 2 && span_lds);
+    const bool lds_rows = LDSROWS || (LDSMODE == 2 && span_lds);
     if (2 * n_area >= nwin) {
         for (int p = threadIdx.x; p < nwin; p += kThreads) {
             if (!wt.isarea[p]) continue;
@@ -650,17 +706,21 @@ void launch_cutout2(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool
 template <int LDSROWS>
 void launch_cutout(const CutArgs &a, dim3 grid, size_t lds, hipStream_t s, bool vec4)
 {
-    const bool fast = a.centered && a.depth_pow2;
-    if (a.dbg_lo) {
-        // test-only variants, no need to specialise further
-        if (a.value_mode == 1) launch_cutout2<LDSROWS, 2, true>(a, grid, lds, s, vec4);
-        else launch_cutout2<LDSROWS, 0, true>(a, grid, lds, s, vec4);
-    } else if (a.value_mode == 1) {
-        launch_cutout2<LDSROWS, 2, false>(a, grid, lds, s, vec4);
-    } else if (fast) {
+    if constexpr (LDSROWS == 3) {      // pair rows: the caller has checked centred / power-of-two depth / exact values / no debug
         launch_cutout2<LDSROWS, 1, false>(a, grid, lds, s, vec4);
     } else {
-        launch_cutout2<LDSROWS, 0, false>(a, grid, lds, s, vec4);
+        const bool fast = a.centered && a.depth_pow2;
+        if (a.dbg_lo) {
+            // test-only variants, no need to specialise further
+            if (a.value_mode == 1) launch_cutout2<LDSROWS, 2, true>(a, grid, lds, s, vec4);
+            else launch_cutout2<LDSROWS, 0, true>(a, grid, lds, s, vec4);
+        } else if (a.value_mode == 1) {
+            launch_cutout2<LDSROWS, 2, false>(a, grid, lds, s, vec4);
+        } else if (fast) {
+            launch_cutout2<LDSROWS, 1, false>(a, grid, lds, s, vec4);
+        } else {
+            launch_cutout2<LDSROWS, 0, false>(a, grid, lds, s, vec4);
+        }
     }
 }
 
@@ -742,6 +802,11 @@ int cutout_launch(const float *scans, int B, int T, int N, const double *tab, in
     dim3 grid((a.Ns + a.tile - 1) / a.tile, B);
     // 16-byte float4 stores / 8-byte half4 stores both need P % 4 == 0 and an aligned base
     const bool vec4 = (num_cutout_pts % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
+    // pair rows (see cutout_kernel): the reference's configuration -- centred output, power-of-two depth, exact values
+    static const bool pair_off = [] { const char *e = std::getenv("POF_CUTOUT_PAIR"); return e && atoi(e) == 0; }();
+    const bool pair = rows_in_lds && centered && a.depth_pow2 && value_mode == 0 && !dbg_lo && !pair_off &&
+                      tbl + 2 * row_bytes <= 64 * 1024;
+    if (pair) { launch_cutout<3>(a, grid, tbl + 2 * row_bytes, s, vec4); POF_CHECK_LAUNCH(); return POF_OK; }
     if (rows_in_lds) launch_cutout<1>(a, grid, lds, s, vec4);
     else if (span_mode) launch_cutout<2>(a, grid, lds, s, vec4);
     else launch_cutout<0>(a, grid, lds, s, vec4);
