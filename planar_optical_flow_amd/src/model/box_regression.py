@@ -35,8 +35,8 @@ def regression_loss2(pred, target, alpha=0.5):
     (``pof::regression_loss2``) instead of a dozen element-wise / reduction kernels each way."""
     if pred.is_cuda and pred.dim() == 2 and pred.shape[1] in (3, 5) and pred.shape[0] > 0 \
             and pred.dtype == torch.float32 and tuple(target.shape) == tuple(pred.shape) and not target.requires_grad:
-        from planar_optical_flow_amd import torch_ops  # noqa: F401  (registers torch.ops.pof.*)
-        return torch.ops.pof.regression_loss2(pred, target.float(), float(alpha))[0]
+        from planar_optical_flow_amd import torch_ops
+        return torch_ops.regression_loss2_fused(pred, target.float(), alpha)
     ori = torch.mean(torch.abs(pred[..., -1] - target[..., -1]))
     if pred.shape[1] == 5:
         z = torch.mean(torch.abs(pred[..., 0] - target[..., 0]))

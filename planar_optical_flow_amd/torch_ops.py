@@ -32,6 +32,30 @@ import torch
 from . import ops
 
 # ------------------------------------------------------------------------------------------------- A9
+_DIRECT = {}
+
+
+def _direct(name, **kw):
+    """``torch.library.custom_op`` that also keeps the plain function: inside an autograd.Function the kernels are
+    called through ``_K`` -- directly in eager mode (a registered op costs ~25 us of dispatcher / wrapper time per call,
+    and the eager box-head step, ~40 such calls for 0.7 ms of kernels, is host-bound), through the registered op with
+    its fake kernel under torch.compile."""
+    def wrap(fn):
+        _DIRECT[name] = fn
+        return torch.library.custom_op("pof::" + name, **kw)(fn)
+    return wrap
+
+
+class _Kernels:
+    def __getattr__(self, name):
+        if torch.compiler.is_compiling():
+            return getattr(torch.ops.pof, name)
+        return _DIRECT[name]
+
+
+_K = _Kernels()
+
+
 @torch.library.custom_op("pof::band_correlation", mutates_args=(), device_types="cuda")
 def band_correlation(f1: torch.Tensor, f2: torch.Tensor, kernel_size: int, max_displacement: int) -> torch.Tensor:
     return ops.band_correlation(f1.contiguous(), f2.contiguous(), kernel_size, max_displacement)
@@ -142,7 +166,7 @@ def _(scans, tab, stride, centered, fixed, window_width, window_depth, num_cutou
 
 
 # ------------------------------------------------------------------------------------------------- N2
-@torch.library.custom_op("pof::conv3_bn_lrelu", mutates_args=(), device_types="cuda")
+@_direct("conv3_bn_lrelu", mutates_args=(), device_types="cuda")
 def conv3_bn_lrelu(x: torch.Tensor, wt: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, pool: bool,
                    negative_slope: float) -> torch.Tensor:
     return ops.conv3_bn_lrelu(x.contiguous(), wt, scale, shift, pool=pool, negative_slope=negative_slope)
@@ -154,7 +178,7 @@ def _(x, wt, scale, shift, pool, negative_slope):
     return x.new_empty((S, wt.shape[2], L // 2 if pool else L))
 
 
-@torch.library.custom_op("pof::conv1d_bn_lrelu", mutates_args=(), device_types="cuda")
+@_direct("conv1d_bn_lrelu", mutates_args=(), device_types="cuda")
 def conv1d_bn_lrelu(x: torch.Tensor, wt: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor, stride: int,
                     negative_slope: float) -> torch.Tensor:
     return ops.conv1d_bn_lrelu(x.contiguous(), wt, scale, shift, stride=stride, negative_slope=negative_slope)
@@ -166,7 +190,7 @@ def _(x, wt, scale, shift, stride, negative_slope):
     return x.new_empty((S, wt.shape[2], (L + stride - 1) // stride))
 
 
-@torch.library.custom_op("pof::linear_bias", mutates_args=(), device_types="cuda")
+@_direct("linear_bias", mutates_args=(), device_types="cuda")
 def linear_bias(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
     return ops.linear_bias(x.contiguous(), weight.contiguous(), bias)
 
@@ -194,7 +218,7 @@ def _linear_backward(ctx, g):
 linear_bias.register_autograd(_linear_backward, setup_context=_linear_setup)
 
 
-@torch.library.custom_op("pof::regression_loss2", mutates_args=(), device_types="cuda")
+@_direct("regression_loss2", mutates_args=(), device_types="cuda")
 def regression_loss2(pred: torch.Tensor, target: torch.Tensor, alpha: float) -> Tuple[torch.Tensor, torch.Tensor]:
     loss, dpred = ops.regression_loss2(pred.contiguous(), target.contiguous(), alpha)
     return loss, dpred
@@ -222,12 +246,50 @@ def linear_small(x, linear):
     ``pof::linear_bias`` when the shape allows (2-D float32 input on the device, in_features a multiple of 4)."""
     if x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and linear.in_features % 4 == 0 \
             and linear.weight.dtype == torch.float32:
-        return torch.ops.pof.linear_bias(x, linear.weight, linear.bias)
+        if torch.compiler.is_compiling():
+            return torch.ops.pof.linear_bias(x, linear.weight, linear.bias)
+        return _LinearSmall.apply(x, linear.weight, linear.bias)
     return linear(x)
 
 
+class _LinearSmall(torch.autograd.Function):
+    """Eager form of pof::linear_bias with its autograd formula (see _direct)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _DIRECT["linear_bias"](x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _linear_backward(ctx, g)
+
+
+class _RegressionLoss2(torch.autograd.Function):
+    """Eager form of pof::regression_loss2 with its autograd formula."""
+
+    @staticmethod
+    def forward(ctx, pred, target, alpha):
+        loss, dpred = _DIRECT["regression_loss2"](pred, target, alpha)
+        ctx.save_for_backward(dpred)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_loss):
+        (dpred,) = ctx.saved_tensors
+        return dpred * g_loss, None, None
+
+
+def regression_loss2_fused(pred, target, alpha):
+    """The box-regression loss (src/model/box_regression.py:52-67) and its gradient in one launch."""
+    if torch.compiler.is_compiling():
+        return torch.ops.pof.regression_loss2(pred, target, float(alpha))[0]
+    return _RegressionLoss2.apply(pred, target, float(alpha))
+
+
 # ------------------------------------------------------------------------------------------------- N2 (training)
-@torch.library.custom_op("pof::bn_lrelu_pool", mutates_args=("running_mean", "running_var"), device_types="cuda")
+@_direct("bn_lrelu_pool", mutates_args=("running_mean", "running_var"), device_types="cuda")
 def bn_lrelu_pool(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
                   running_var: Optional[torch.Tensor], momentum: float, eps: float, negative_slope: float,
                   pool: bool, groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -242,7 +304,7 @@ def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, 
     return (y.new_empty((S, C, L // 2 if pool else L)), y.new_empty((groups * C,)), y.new_empty((groups * C,)))
 
 
-@torch.library.custom_op("pof::bn_lrelu_pool_backward", mutates_args=(), device_types="cuda")
+@_direct("bn_lrelu_pool_backward", mutates_args=(), device_types="cuda")
 def bn_lrelu_pool_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                            mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, pool: bool,
                            bias_grad: bool, groups: int = 1
@@ -260,7 +322,7 @@ def _(y, dz, gamma, beta, mean, invstd, negative_slope, pool, bias_grad, groups=
             gamma.new_empty((gamma.shape[0] if bias_grad else 0,)))
 
 
-@torch.library.custom_op("pof::bn_lrelu_rowmax", mutates_args=("running_mean", "running_var"), device_types="cuda")
+@_direct("bn_lrelu_rowmax", mutates_args=("running_mean", "running_var"), device_types="cuda")
 def bn_lrelu_rowmax(y: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, running_mean: Optional[torch.Tensor],
                     running_var: Optional[torch.Tensor], momentum: float, eps: float, negative_slope: float,
                     groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -277,7 +339,7 @@ def _(y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, 
     return (y.new_empty((S, C)), y.new_empty((groups * C,)), y.new_empty((groups * C,)))
 
 
-@torch.library.custom_op("pof::bn_lrelu_rowmax_backward", mutates_args=(), device_types="cuda")
+@_direct("bn_lrelu_rowmax_backward", mutates_args=(), device_types="cuda")
 def bn_lrelu_rowmax_backward(y: torch.Tensor, dz: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor,
                              mean: torch.Tensor, invstd: torch.Tensor, negative_slope: float, bias_grad: bool,
                              groups: int = 1) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
@@ -301,7 +363,7 @@ class BnLreluPool(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, momentum, eps, negative_slope, pool):
-        z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+        z, mean, invstd = _K.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
                                                       negative_slope, pool)
         ctx.save_for_backward(y, gamma, beta, mean, invstd)
         ctx.negative_slope, ctx.pool = negative_slope, pool
@@ -310,7 +372,7 @@ class BnLreluPool(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_z):
         y, gamma, beta, mean, invstd = ctx.saved_tensors
-        dy, dgamma, dbeta, _ = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
+        dy, dgamma, dbeta, _ = _K.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
                                                                     ctx.negative_slope, ctx.pool, False)
         return dy, dgamma, dbeta, None, None, None, None, None, None
 
@@ -340,7 +402,7 @@ def bn_lrelu_pool_train(y, bn, negative_slope=0.1, pool=False):
     return BnLreluPool.apply(y, bn.weight, bn.bias, rm, rv, momentum, eps, float(negative_slope), bool(pool))
 
 
-@torch.library.custom_op("pof::conv3_wgrad", mutates_args=(), device_types="cuda")
+@_direct("conv3_wgrad", mutates_args=(), device_types="cuda")
 def conv3_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return ops.conv3_wgrad(x.contiguous(), dy.contiguous())
 
@@ -350,7 +412,7 @@ def _(x, dy):
     return x.new_empty((dy.shape[1], x.shape[1], 3))
 
 
-@torch.library.custom_op("pof::conv1_wgrad", mutates_args=(), device_types="cuda")
+@_direct("conv1_wgrad", mutates_args=(), device_types="cuda")
 def conv1_wgrad(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return ops.conv3_wgrad(x.contiguous(), dy.contiguous(), kernel_size=1)
 
@@ -393,14 +455,14 @@ def _pointwise_weight_grad(x, dy, weight):
     S, ci, L = (int(v) for v in x.shape)       # (int: a symbolic size under torch.compile is specialised here)
     co = int(dy.shape[1])
     if _wgrad_supported(S, ci, co, L, 1):
-        return torch.ops.pof.conv1_wgrad(x, dy)
+        return _K.conv1_wgrad(x, dy)
     for lc in (64, 56, 48, 40, 32, 24, 16):
         nc = -(-L // lc)
         if _wgrad_supported(S * nc, ci, co, lc, 1):
             pad = nc * lc - L
             xc = torch.nn.functional.pad(x, (0, pad)).reshape(S, ci, nc, lc).permute(0, 2, 1, 3).reshape(S * nc, ci, lc)
             dyc = torch.nn.functional.pad(dy, (0, pad)).reshape(S, co, nc, lc).permute(0, 2, 1, 3).reshape(S * nc, co, lc)
-            return torch.ops.pof.conv1_wgrad(xc.contiguous(), dyc.contiguous())
+            return _K.conv1_wgrad(xc.contiguous(), dyc.contiguous())
     return torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [0], [1], False, [0], 1,
                                                [False, True, False])[1]
 
@@ -414,7 +476,7 @@ def _weight_grad(x, dy, weight):
     S, ci, L = (int(v) for v in x.shape)
     co = int(dy.shape[1])
     if _wgrad_supported(S, ci, co, L, 3):
-        return torch.ops.pof.conv3_wgrad(x, dy)
+        return _K.conv3_wgrad(x, dy)
     for lc in (62, 54, 46, 38, 30, 22, 14):
         nc = -(-L // lc)
         if _wgrad_supported(S * nc, ci, co, lc + 2, 3):
@@ -422,7 +484,7 @@ def _weight_grad(x, dy, weight):
             xc = xp.unfold(2, lc + 2, lc).permute(0, 2, 1, 3).reshape(S * nc, ci, lc + 2)
             dyc = torch.nn.functional.pad(torch.nn.functional.pad(dy, (0, nc * lc - L)).reshape(S, co, nc, lc), (1, 1))
             dyc = dyc.permute(0, 2, 1, 3).reshape(S * nc, co, lc + 2)
-            return torch.ops.pof.conv3_wgrad(xc.contiguous(), dyc.contiguous())
+            return _K.conv3_wgrad(xc.contiguous(), dyc.contiguous())
     return torch.ops.aten.convolution_backward(dy, x, weight, None, [1], [1], [1], False, [0], 1,
                                                [False, True, False])[1]
 
@@ -489,7 +551,7 @@ class Conv3Train(torch.autograd.Function):
         co = weight.shape[0]
         wt, wd = _weight_layouts(weight, ctx.needs_input_grad[0])
         shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
-        y = torch.ops.pof.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
+        y = _K.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
         ctx.save_for_backward(x, weight, wd)
         ctx.has_bias = bias is not None
         return y
@@ -501,7 +563,7 @@ class Conv3Train(torch.autograd.Function):
         gy = gy.contiguous()
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.pof.conv3_bn_lrelu(gy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
+            dx = _K.conv3_bn_lrelu(gy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         dw = _weight_grad(x, gy, weight) if ctx.needs_input_grad[1] else None
         db = gy.sum(dim=(0, 2)) if ctx.has_bias and ctx.needs_input_grad[2] else None
         return dx, dw, db
@@ -525,8 +587,8 @@ class TrunkUnitTrain(torch.autograd.Function):
         co = weight.shape[0]
         wt, wd = _weight_layouts(weight, ctx.needs_input_grad[0])
         shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
-        y = torch.ops.pof.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
-        z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+        y = _K.conv3_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, False, 1.0)
+        z, mean, invstd = _K.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
                                                       negative_slope, pool, groups)
         ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd, wd)
         ctx.has_bias, ctx.negative_slope, ctx.pool, ctx.groups = bias is not None, negative_slope, pool, groups
@@ -537,11 +599,11 @@ class TrunkUnitTrain(torch.autograd.Function):
         x, weight, y, gamma, beta, mean, invstd, wd = ctx.saved_tensors
         co, ci, _ = weight.shape
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
+        dy, dgamma, dbeta, db = _K.bn_lrelu_pool_backward(y, g_z, gamma, beta, mean, invstd,
                                                                      ctx.negative_slope, ctx.pool, want_db, ctx.groups)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.pof.conv3_bn_lrelu(dy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
+            dx = _K.conv3_bn_lrelu(dy, wd, _const(ci, 1.0, weight), _const(ci, 0.0, weight), False, 1.0)
         dw = None
         if ctx.needs_input_grad[1]:
             dw = _weight_grad(x, dy, weight)
@@ -581,12 +643,12 @@ class ConvUnitTrain(torch.autograd.Function):
         co, ci, k = weight.shape
         wt = weight.detach().permute(2, 1, 0).contiguous()
         shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
-        y = torch.ops.pof.conv1d_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, stride, 1.0)
+        y = _K.conv1d_bn_lrelu(x, wt, _const(co, 1.0, weight), shift, stride, 1.0)
         if rowmax:      # z [S, Co] = max over the positions, taken inside the tail's apply pass
-            z, mean, invstd = torch.ops.pof.bn_lrelu_rowmax(y, gamma, beta, running_mean, running_var, momentum, eps,
+            z, mean, invstd = _K.bn_lrelu_rowmax(y, gamma, beta, running_mean, running_var, momentum, eps,
                                                             negative_slope, groups)
         else:
-            z, mean, invstd = torch.ops.pof.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
+            z, mean, invstd = _K.bn_lrelu_pool(y, gamma, beta, running_mean, running_var, momentum, eps,
                                                           negative_slope, False, groups)
         ctx.save_for_backward(x, weight, y, gamma, beta, mean, invstd)
         ctx.has_bias, ctx.negative_slope, ctx.stride, ctx.groups = bias is not None, negative_slope, stride, groups
@@ -600,10 +662,10 @@ class ConvUnitTrain(torch.autograd.Function):
         stride = ctx.stride
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.rowmax:
-            dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_rowmax_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
+            dy, dgamma, dbeta, db = _K.bn_lrelu_rowmax_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
                                                                            ctx.negative_slope, want_db, ctx.groups)
         else:
-            dy, dgamma, dbeta, db = torch.ops.pof.bn_lrelu_pool_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
+            dy, dgamma, dbeta, db = _K.bn_lrelu_pool_backward(y, g_z.contiguous(), gamma, beta, mean, invstd,
                                                                          ctx.negative_slope, False, want_db, ctx.groups)
         one, zero = _const(ci, 1.0, weight), _const(ci, 0.0, weight)
         w = weight.detach()
@@ -611,16 +673,16 @@ class ConvUnitTrain(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if k == 3 and stride == 1:
-                dx = torch.ops.pof.conv1d_bn_lrelu(dy, w.flip(2).permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
+                dx = _K.conv1d_bn_lrelu(dy, w.flip(2).permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
             elif k == 1:
-                dx = torch.ops.pof.conv1d_bn_lrelu(dy, w.permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
+                dx = _K.conv1d_bn_lrelu(dy, w.permute(2, 0, 1).contiguous(), one, zero, 1, 1.0)
             else:
                 dx = torch.empty_like(x)
                 w1 = w[:, :, 1:2].permute(2, 0, 1).contiguous()                                  # [1, Co, Ci]
-                dx[:, :, 0::2] = torch.ops.pof.conv1d_bn_lrelu(dy, w1, one, zero, 1, 1.0)     # even positions: lo of them
+                dx[:, :, 0::2] = _K.conv1d_bn_lrelu(dy, w1, one, zero, 1, 1.0)     # even positions: lo of them
                 if lin > 1:
                     wo = torch.stack((torch.zeros_like(w[:, :, 0]), w[:, :, 2], w[:, :, 0]), dim=0)   # taps dy[l-1], dy[l], dy[l+1]
-                    dxo = torch.ops.pof.conv1d_bn_lrelu(dy, wo.contiguous(), one, zero, 1, 1.0)
+                    dxo = _K.conv1d_bn_lrelu(dy, wo.contiguous(), one, zero, 1, 1.0)
                     dx[:, :, 1::2] = dxo[:, :, :lin // 2]
         if ctx.needs_input_grad[1]:
             if k == 3 and stride == 1:
@@ -668,7 +730,7 @@ class Conv1dTrain(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         co, ci, k = weight.shape
         shift = bias.detach() if bias is not None else _const(co, 0.0, weight)
-        y = torch.ops.pof.conv1d_bn_lrelu(x, weight.detach().permute(2, 1, 0).contiguous(), _const(co, 1.0, weight), shift,
+        y = _K.conv1d_bn_lrelu(x, weight.detach().permute(2, 1, 0).contiguous(), _const(co, 1.0, weight), shift,
                                           1, 1.0)
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
@@ -681,7 +743,7 @@ class Conv1dTrain(torch.autograd.Function):
         dy = dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = torch.ops.pof.conv1d_bn_lrelu(dy, weight.detach().permute(2, 0, 1).contiguous(), _const(ci, 1.0, weight),
+            dx = _K.conv1d_bn_lrelu(dy, weight.detach().permute(2, 0, 1).contiguous(), _const(ci, 1.0, weight),
                                                _const(ci, 0.0, weight), 1, 1.0)
         if ctx.needs_input_grad[1]:
             dw = _pointwise_weight_grad(x, dy, weight)

@@ -21,5 +21,18 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_trace_$TAG -- p
 cp $(find /tmp/pof_trace_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_trace1_$TAG -- python3 bench.py --steps 24 --warmup 8 --slots 1 --no-cpu-baseline --no-extra > $OUT/bench_traced_single_slot.json 2> $OUT/trace1.err
 cp $(find /tmp/pof_trace1_$TAG -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats_single_slot.csv
+# configs[3] training step as one graph replay (HIP units / library modules), the ordered kernels of one eager step, and
+# the Prototype's training + inference trace (no library convolution kernel may appear)
+cd /tmp
+for m in hip modules; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_bh_${m}_$TAG -- python3 $GRAFT_REPO_ROOT/tools/trace_boxhead.py $m > $GRAFT_REPO_ROOT/$OUT/boxhead_$m.log 2>&1
+  cp $(find /tmp/pof_bh_${m}_$TAG -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$OUT/boxhead_graphed_${m}_kernel_stats.csv
+done
+rocprofv3 --kernel-trace --output-format csv -d /tmp/pof_bhe_$TAG -- python3 $GRAFT_REPO_ROOT/tools/trace_boxhead_eager.py hip > /dev/null 2>&1
+python3 $GRAFT_REPO_ROOT/tools/trace_order.py $(find /tmp/pof_bhe_$TAG -name "*kernel_trace.csv" | head -1) > $GRAFT_REPO_ROOT/$OUT/boxhead_step_order.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pof_pt_$TAG -- python3 $GRAFT_REPO_ROOT/tools/trace_prototype.py > $GRAFT_REPO_ROOT/$OUT/prototype_trace.log 2>&1
+cp $(find /tmp/pof_pt_$TAG -name "*kernel_stats.csv" | head -1) $GRAFT_REPO_ROOT/$OUT/prototype_kernel_stats.csv
+cd $GRAFT_REPO_ROOT
+echo "model traces done" >> $OUT/progress.txt
 (lscpu | grep -E "Model name|^CPU\(s\)|Thread|Core|Socket"; echo "cgroup cpu.max: $(cat /sys/fs/cgroup/cpu.max 2>/dev/null)"; nproc; rocminfo | grep -E "Marketing Name|Compute Unit|Max Clock" | head -8) > $OUT/host.txt
 cat $OUT/bench.json | head -c 3000
