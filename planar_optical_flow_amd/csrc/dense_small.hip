@@ -5,7 +5,7 @@
 //
 // at the head's batch (256 rows).  These are 0.07-0.27 GFLOP problems: what they cost is a launch and a latency chain,
 // and the BLAS library's choice for an output of at most 256 x 256 is ONE 256 x 256 tile on one CU -- fc2 takes
-// 118 us there (tools/exp_fc2.py: 257 rows or 264 columns take 19 us), 12 % of the whole training step.
+// 118 us there (tools/bench_dense_small.py: 257 rows or 264 columns take 19 us), 12 % of the whole training step.
 //
 // Here: float32 MFMA (v_mfma_f32_32x32x2_f32), one workgroup per 32 x 32 output tile, its four waves split K
 // (8-element chunks dealt round-robin) and meet in LDS; wave 0 adds them in wave order -- deterministic, no atomics.

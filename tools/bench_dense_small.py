@@ -1,4 +1,5 @@
-"""Experiment (round 3): the fc2 GEMM of the box head (256 x 512 -> 256), 118 us under hipBLASLt's choice."""
+"""The dense layers of the box head at batch 256 (fc1 1024 -> 512, fc2 512 -> 256, fc3 256 -> 3): the BLAS library's forward
+in several formulations, sizes around the single-tile hole (an output of at most 256 x 256: 118 us), and pof_linear_bias."""
 import os
 import sys
 
@@ -44,6 +45,11 @@ cands["K halves, contiguous"] = lambda: torch.addmm(F.linear(h1, W1, b), h2, W2.
 for name, f in cands.items():
     out = f()
     print("   %-26s %7.1f us   max err %.2e" % (name, timeit(f), float((out.double() - ref).abs().max())))
+for (bb, kk, nn) in ((256, 1024, 512), (256, 512, 256), (256, 256, 3)):
+    hh, ww, bv = torch.randn(bb, kk, device=dev), torch.randn(nn, kk, device=dev), torch.randn(nn, device=dev)
+    out = torch.empty(bb, nn, device=dev)
+    print("   pof_linear_bias %4d x %4d -> %4d  %7.1f us (eager launch rate; ~5 us as a graph node)"
+          % (bb, kk, nn, timeit(lambda: ops.linear_bias(hh, ww, bv, out=out))))
 dy = torch.randn(B, N, device=dev)
 print("   dgrad dy W               %7.1f us" % timeit(lambda: torch.mm(dy, W)))
 print("   wgrad dy^T h             %7.1f us" % timeit(lambda: torch.mm(dy.t(), h)))
