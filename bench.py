@@ -86,6 +86,8 @@ def parse():
     ap.add_argument("--no-params", action="store_true",
                     help="ablation: the timed launches do not evaluate the next slots' params (they are constant)")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-arena", dest="arena", action="store_false",
+                    help="allocate every ring tensor on its own instead of carving the ring out of one allocation")
     ap.add_argument("--slots", type=int, default=8,
                     help="ring slots (batches) handed to ONE launch of pof_scan_preprocess_multi; a step is still one "
                          "batch: K steps = ceil(K / slots) launches (1: one launch per batch)")
@@ -286,25 +288,51 @@ def main():
         over ranks.  -> dict(wall_s [repeats], dev_ms [repeats], ring)"""
         Bm = len(sbm.scans)
         offs, rphi, _ = sbm.det_csr()
-        S = max(1, min(slots, a.ring // 2, 8))
-        ring = []
+        S = max(1, min(slots, a.ring // 2, ops.SCAN_MAX_SLOTS))
+        # the ring's slots are carved out of ONE allocation (what a loader's ring buffer is): a single large mapping
+        # gets larger translation fragments than a few hundred separate tensors
+        esz = torch.empty((), dtype=out_dtype).element_size()
+        ws_bytes = [0] * a.ring
+        plan = []
         for r in range(a.ring):
             sh = (r * 509) % Bm  # distinct memory and distinct content per ring slot
-            scans = torch.from_numpy(np.roll(sbm.scans, sh, axis=0)).to(dev)
-            o0 = torch.from_numpy(np.roll(sbm.odom0, sh, axis=0)).to(dev)
-            o1 = torch.from_numpy(np.roll(sbm.odom1, sh, axis=0)).to(dev)
             counts = np.roll(np.diff(offs), sh)
             order = np.roll(np.arange(Bm), sh)
             ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
             rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
+            plan.append((sh, ro, rr))
+            ws_bytes[r] = ops.scan_preprocess_workspace_bytes(Bm, int(len(rr)))
+        Tn = sbm.scans.shape[1]
+
+        def rup(n):
+            return (n + 255) // 256 * 256
+        per_slot = [rup(Bm * Tn * N * 4) + rup(Bm * N * 2 * esz) + rup(Bm * N * 8) + rup(Bm * N * 2 * 4) + rup(Bm * N * 4)
+                    + rup(ws_bytes[r]) for r in range(a.ring)]
+        arena = torch.empty(sum(per_slot), dtype=torch.uint8, device=dev) if a.arena else None
+        cursor = [0]
+
+        def carve(shape, dtype):
+            n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+            if arena is None:
+                return torch.empty(shape, dtype=dtype, device=dev)
+            t = arena[cursor[0]:cursor[0] + n].view(dtype).view(shape)
+            cursor[0] += rup(n)
+            return t
+        ring = []
+        for r in range(a.ring):
+            sh, ro, rr = plan[r]
+            scans = carve(tuple(sbm.scans.shape), torch.float32)
+            scans.copy_(torch.from_numpy(np.roll(sbm.scans, sh, axis=0)))
+            o0 = torch.from_numpy(np.roll(sbm.odom0, sh, axis=0)).to(dev)
+            o1 = torch.from_numpy(np.roll(sbm.odom1, sh, axis=0)).to(dev)
             det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
             outs = {
-                "flow": torch.empty((Bm, N, 2), dtype=out_dtype, device=dev),
-                "target_cls": torch.empty((Bm, N), dtype=torch.int64, device=dev),
-                "target_reg": torch.empty((Bm, N, 2), dtype=torch.float32, device=dev),
-                "exclude_mask": torch.empty((Bm, N), dtype=torch.float32, device=dev),
+                "flow": carve((Bm, N, 2), out_dtype),
+                "target_cls": carve((Bm, N), torch.int64),
+                "target_reg": carve((Bm, N, 2), torch.float32),
+                "exclude_mask": carve((Bm, N), torch.float32),
             }
-            ws = torch.empty(ops.scan_preprocess_workspace_bytes(Bm, int(det.rphi.shape[0])), dtype=torch.uint8, device=dev)
+            ws = carve((ws_bytes[r],), torch.uint8)
             ring.append({"scans": scans, "odom0": o0, "odom1": o1, "dets": det, "out": outs, "workspace": ws})
 
         def trip(n):

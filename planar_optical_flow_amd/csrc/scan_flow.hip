@@ -797,7 +797,10 @@ struct FlatArgs {
     float m_dyn;            // max_c (1e-3 + 1e-4 sd_c), rounded up
     float thr_assoc;        // max_c (sa_c - sd_c) + m_assoc, rounded up
     float m_assoc;          // max_c (1e-3 + 1e-4 max(sd_c, sa_c)) + the rounding of (sa - sd) to float32, rounded up
-    int pad_;
+    int uni_waves;          // wave-chunks per batch when every batch of the launch has the same count, else 0
+    unsigned uni_m;         // w / uni_waves = mulhi(w, uni_m) >> uni_s (the slot of wave-chunk w without a search)
+    int uni_s;
+    int pad_[2];
     int wave0[kMaxSlots];   // first wave-chunk of each batch
     FlatBatch b[kMaxSlots];
 };
@@ -805,6 +808,9 @@ struct FlatArgs {
 struct ParamsMulti {
     int nb;
     int first, total;          // the params blocks are blocks [first, first + total) of the grid
+    int uni_blocks;            // params blocks per batch when all batches have the same count, else 0
+    unsigned uni_m;            // blk / uni_blocks = mulhi(blk, uni_m) >> uni_s
+    int uni_s;
     int blk0[kMaxSlots + 1];   // first params block of each batch (unused slots: the total); blk0[kMaxSlots] = total
     PreArgs p[kMaxSlots];
 };
@@ -1174,13 +1180,17 @@ __global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L,
 #ifndef POF_FLAT_NO_PARAMS
             // a params block belongs to ONE batch (uniform slot index -> scalar loads of its arguments)
             const int blk = sblock - P.first;
-            int k = 0;
+            int k = 0, b0 = P.blk0[0];
+            if (P.uni_blocks) {      // equal batches (a loader's ring): the slot is a division, not a search
+                k = (int)(__umulhi((unsigned)blk, P.uni_m) >> P.uni_s);
+                b0 = k * P.uni_blocks;
+            } else {
 #pragma unroll
-            for (int i = 1; i < kMaxSlots; ++i) k += (blk >= P.blk0[i]) ? 1 : 0;
-            k = __builtin_amdgcn_readfirstlane(k);
-            int b0 = P.blk0[0];
+                for (int i = 1; i < kMaxSlots; ++i) k += (blk >= P.blk0[i]) ? 1 : 0;
+                k = __builtin_amdgcn_readfirstlane(k);
 #pragma unroll
-            for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
+                for (int i = 1; i < kMaxSlots; ++i) b0 = (k >= i) ? P.blk0[i] : b0;
+            }
             const auto *pa = reinterpret_cast<const __attribute__((address_space(4))) PreArgs *>(
                 ka + kFlatArgsKernargBytes + offsetof(ParamsMulti, p) + (size_t)k * sizeof(PreArgs));
             params_work<false, false>(pa, (blk - b0) * THREADS + (int)threadIdx.x);   // jobs past the batch's count do nothing
@@ -1193,10 +1203,18 @@ __global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L,
     const int lane = (int)threadIdx.x & 63;
     const int w = sblock * WAVES + wv;
     if (w >= L.total_waves) return;
-    // batch of this wave-chunk: wave0[i] of the unused slots is INT_MAX
+    // batch of this wave-chunk: a division when the batches are equal (a loader's ring), else the search; wave0[i] of
+    // the unused slots is INT_MAX.  (More slots per launch were tried -- kernel arguments of 12 KB launch fine,
+    // tools/ubench/kernarg_size.hip -- and gain nothing: a ring of 2 x 20 batches is a 2.4 GB working set, beyond the
+    // reach of the address translation caches, and the step goes from 11 to 14-15 us; profiles/r3_headline_ring.txt)
     int k = 0;
+    if (L.uni_waves) {
+        k = (int)(__umulhi((unsigned)w, L.uni_m) >> L.uni_s);
+    } else {
 #pragma unroll
-    for (int i = 1; i < kMaxSlots; ++i) k += (w >= L.wave0[i]) ? 1 : 0;
+        for (int i = 1; i < kMaxSlots; ++i) k += (w >= L.wave0[i]) ? 1 : 0;
+    }
+    k = __builtin_amdgcn_readfirstlane(k);
     const FlatBatch bt = kernarg_struct<FlatBatch>(ka + offsetof(FlatArgs, b) + (size_t)k * sizeof(FlatBatch));
     const FlatCfg<CFG> cfg{L.flags};
     unsigned char *lds = smem[wv];
@@ -1538,6 +1556,15 @@ int bind_next(const pof_scan_inputs *next, PreArgs &nx, int *jobs)
     return POF_OK;
 }
 
+// x / d = mulhi(x, m) >> sh for 0 <= x < 2^31 and 2 <= d < 2^31 (m = ceil(2^(31 + L) / d), L = ceil(log2 d), sh = L - 1)
+void magic_u31(unsigned d, unsigned *m, int *sh)
+{
+    int lg = 1;
+    while ((1u << lg) < d) ++lg;
+    *m = (unsigned)(((1ull << (31 + lg)) + d - 1) / d);
+    *sh = lg - 1;
+}
+
 // One launch: stream n_cur batches (same N, same set of outputs) and evaluate the params of n_next batches.
 int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_scan_inputs *const *next, int n_next,
                 hipStream_t s)
@@ -1581,6 +1608,13 @@ int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_
     }
     for (int i = n_cur; i < kMaxSlots; ++i) L.wave0[i] = 0x7fffffff;
     L.total_waves = (int)waves;
+    L.uni_waves = 0; L.uni_m = 0; L.uni_s = 0;
+    if (n_cur > 0 && waves % n_cur == 0) {
+        const long long per = waves / n_cur;
+        bool same = per > 1;
+        for (int i = 0; i < n_cur && same; ++i) same = L.wave0[i] == (int)(per * i);
+        if (same) { L.uni_waves = (int)per; magic_u31((unsigned)per, &L.uni_m, &L.uni_s); }
+    }
     const int wpb = threads / 64;
     L.main_blocks = (int)((waves + wpb - 1) / wpb);
     ParamsMulti P = {};
@@ -1599,6 +1633,13 @@ int launch_flat(const FlatBatch *cur, int n_cur, const FlatCommon &c, const pof_
     }
     for (int i = P.nb; i <= kMaxSlots; ++i) P.blk0[i] = extra;
     P.total = extra;
+    P.uni_blocks = 0; P.uni_m = 0; P.uni_s = 0;
+    if (P.nb > 0 && extra % P.nb == 0) {
+        const int per = extra / P.nb;
+        bool same = per > 1;
+        for (int i = 0; i < P.nb && same; ++i) same = P.blk0[i] == per * i;
+        if (same) { P.uni_blocks = per; magic_u31((unsigned)per, &P.uni_m, &P.uni_s); }
+    }
     P.first = (int)((long long)L.main_blocks * ppos / 100);
     if (L.main_blocks + extra == 0) return POF_OK;
     dim3 grid((unsigned)(L.main_blocks + extra));

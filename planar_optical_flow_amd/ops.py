@@ -238,10 +238,13 @@ def _scan_inputs(nb, want, flow_kind, assoc_radius, labels, dyn_radius, need_det
     return nxt
 
 
+SCAN_MAX_SLOTS = _lib.SCAN_MAX_SLOTS     # batches one launch of scan_preprocess_multi may stream (and evaluate params for)
+
+
 def scan_preprocess_multi(batches, tab, next_batches=(), flow_kind=FLOW_DISPLACEMENT, canonical=True,
                           out_dtype=torch.float32, want=("flow",), assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3),
                           dyn_radius=(2.5, 2.0, 2.0)):
-    """A2-A7 fused for up to 8 batches in ONE launch (pof_scan_preprocess_multi): a loader that runs ahead hands
+    """A2-A7 fused for up to SCAN_MAX_SLOTS (8) batches in ONE launch (pof_scan_preprocess_multi): a loader that runs ahead hands
     over several ring slots at once.
 
     batches: list of dict(scans [B,T,N] | [B,N], dets (DetCSR or None), out {name: tensor}, workspace) -- the

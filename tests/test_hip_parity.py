@@ -704,6 +704,54 @@ def test_multi_batch_launch_equals_single_calls(ops, out_dtype):
     assert hits > 0
 
 
+def test_multi_batch_launch_many_slots(ops):
+    """A full launch (POF_SCAN_MAX_SLOTS = 8 batches of different sizes: the slot of a wave is found by the search)
+    after ONE params launch == a call per batch, bit for bit; one slot too many is refused; equal batches (the slot
+    is a division) likewise."""
+    tab = ops.phi_table()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+    slots = []
+    for k in range(8):
+        B = 3 + 41 * k
+        sb = synth.make_batch(seed=200 + k, B=B, T=2, max_legs=5, mixed_classes=(k % 3 == 0))
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(B, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        out = {"flow": torch.full((B, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "target_cls": torch.full((B, 450), -1, dtype=torch.int64, device=DEV),
+               "target_reg": torch.full((B, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "exclude_mask": torch.full((B, 450), 7.0, dtype=torch.float32, device=DEV)}
+        slots.append({"scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det, "workspace": ws,
+                      "out": out})
+    ref = [ops.scan_preprocess(s["scans"], tab, s["odom0"], s["odom1"], s["dets"], want=want) for s in slots]
+    ops.scan_preprocess_multi([], tab, next_batches=slots, want=want)
+    ops.scan_preprocess_multi(slots, tab, want=want)
+    for k, s in enumerate(slots):
+        for name in want:
+            assert torch.equal(s["out"][name], ref[k][name]), (k, name)
+    assert ops.SCAN_MAX_SLOTS == 8
+    with pytest.raises(ValueError):
+        ops.scan_preprocess_multi(slots + slots[:1], tab, want=want)
+    # equal batches (a loader's ring): the slot of a wave is found by a division instead of the search
+    eq = []
+    for k in range(6):
+        sb = synth.make_batch(seed=300 + k, B=257, T=2, max_legs=6, mixed_classes=(k % 2 == 0))
+        # the same number of detections in every batch, so that the params blocks are uniform too
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(257, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        out = {"flow": torch.full((257, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "target_cls": torch.full((257, 450), -1, dtype=torch.int64, device=DEV),
+               "target_reg": torch.full((257, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "exclude_mask": torch.full((257, 450), 7.0, dtype=torch.float32, device=DEV)}
+        eq.append({"scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det, "workspace": ws, "out": out})
+    ref = [ops.scan_preprocess(s["scans"], tab, s["odom0"], s["odom1"], s["dets"], want=want) for s in eq]
+    ops.scan_preprocess_multi([], tab, next_batches=eq[:3], want=want)
+    ops.scan_preprocess_multi(eq[:3], tab, next_batches=eq[3:], want=want)
+    ops.scan_preprocess_multi(eq[3:], tab, want=want)
+    for k, s in enumerate(eq):
+        for name in want:
+            assert torch.equal(s["out"][name], ref[k][name]), ("equal batches", k, name)
+
+
 def test_params_sincos_domain(ops):
     """The params jobs evaluate sincos with a medium-range reduction (|angle| < 2^19 pi/2 ~ 8.2e5 rad).  Inside the
     range: headings of hundreds of radians and bearings anywhere in the field of view agree with the oracle
