@@ -1205,8 +1205,8 @@ __global__ __launch_bounds__(THREADS, 8) void scan_flat_kernel(const FlatArgs L,
     if (w >= L.total_waves) return;
     // batch of this wave-chunk: a division when the batches are equal (a loader's ring), else the search; wave0[i] of
     // the unused slots is INT_MAX.  (More slots per launch were tried -- kernel arguments of 12 KB launch fine,
-    // tools/ubench/kernarg_size.hip -- and gain nothing: a ring of 2 x 20 batches is a 2.4 GB working set, beyond the
-    // reach of the address translation caches, and the step goes from 11 to 14-15 us; profiles/r3_headline_ring.txt)
+    // tools/ubench/kernarg_size.hip -- and gain nothing: with more than ~1 GB of resident ring slots (2 x 20 batches:
+    // 2.4 GB) the step goes from 11 to 14-15 us whatever the launch shape; profiles/r3_headline_ring.txt)
     int k = 0;
     if (L.uni_waves) {
         k = (int)(__umulhi((unsigned)w, L.uni_m) >> L.uni_s);
