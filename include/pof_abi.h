@@ -454,6 +454,18 @@ int pof_bn_lrelu_pool_backward(const float *y, const float *dz, long long S, int
                                float *dgamma, float *dbeta, float *dbias_in, void *workspace,
                                size_t workspace_bytes, pof_stream_t stream);
 
+/* The trunk's first TWO units in one launch (inference): x [S][L] float32 is the single-channel
+ * cutout (dr_spaam.py:86-92, conv_block_1[0] and [1]); the C1 channels of the first unit,
+ * lrelu_slope1(a0 x[q-1] + a1 x[q] + a2 x[q+1] + b) with l1[c] = {a0, a1, a2, b} (its taps times its
+ * folded BatchNorm scale, and its shift; zero padding at the sequence borders), are computed inside
+ * the second unit's kernel instead of being written and read back (1 GB each way at B = 32).  wt
+ * [3][C1][Co], scale / shift [Co], pool, negative_slope: the second unit, as in pof_conv3_bn_lrelu.
+ * C1 <= 128.  The first unit's sums are FMA chains here and MFMA accumulations in the two-launch
+ * form: results agree to float32 round-off, not bit for bit. */
+int pof_conv3_first_two(const float *x, const float *l1, double slope1, const float *wt, const float *scale,
+                        const float *shift, int S, int C1, int Co, int L, int pool, double negative_slope,
+                        float *out, pof_stream_t stream);
+
 /* ----------------------------------------------------------------------
  * N2 trunk convolution, weight gradient         src/depracted/model/dr_spaam.py:8-19
  * dw[co][ci][t] = sum_{s,l} dy[s][co][l] * x[s][ci][l + t - 1]  (Conv1d k = 3, pad = 1):

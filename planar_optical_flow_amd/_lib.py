@@ -64,6 +64,7 @@ SIGNATURES = {
     "pof_bn_lrelu_pool_backward": (_i, [_p, _p, _ll, _i, _i, _i, _p, _p, _p, _p, _d, _i, _p, _p, _p, _p, _p, _sz, _p]),
     "pof_conv3_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "pof_conv3_wgrad": (_i, [_p, _p, _i, _i, _i, _i, _p, _p, _sz, _p]),
+    "pof_conv3_first_two": (_i, [_p, _p, _d, _p, _p, _p, _i, _i, _i, _i, _i, _d, _p, _p]),
     "pof_regression_loss2": (_i, [_p, _p, _ll, _i, _d, _p, _p, _p]),
     "pof_linear_bias": (_i, [_p, _p, _p, _i, _i, _i, _p, _p]),
     "pof_conv1d_wgrad_workspace_bytes": (_sz, [_i, _i, _i, _i, _i]),

@@ -40,6 +40,11 @@ struct ConvArgs {
     int S, Ci, Co, L, pool;
     int Lc;               // positions the convolution produces per sequence: L (stride 1), (L + 1) / 2 (stride 2)
     float slope;
+    // FUSE1 (the trunk's first two layers in one launch): x is the single-channel input [S][L]; input channel c of
+    // this convolution is computed on the fly, lrelu(a0 x[q-1] + a1 x[q] + a2 x[q+1] + b) with l1[c] = {a0, a1, a2, b}
+    // (the first layer's taps times its folded BatchNorm scale, and its shift), slope1 its LeakyReLU slope
+    const float *l1;      // [Ci][4]
+    float slope1;
 };
 
 // Epilogue shared by both kernels.  C/D layout of v_mfma_f32_32x32x2_f32: column n = lane & 31,
@@ -88,9 +93,13 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs &a, const f32x16 (&
 
 // KW taps (1 or 3, padding KW / 2), STRIDE 1 or 2 (round 3: the Prototype's stride-2 encoders and the point-wise heads
 // leave the library as well); the DR-SPAAM trunk is <CT, 3, 1>.
-template <int CT, int KW, int STRIDE>
+// FUSE1: the DR-SPAAM trunk's first layer (1 -> 64, 0.3 ms of pure 1 GB write at B = 32, read back by the second
+// layer) is folded into the second: the B operand of channel c is three FMAs, a multiply and a max on the lane's five
+// input values instead of a global load -- a few hundred vector instructions per wave in the shadow of its MFMAs.
+template <int CT, int KW, int STRIDE, bool FUSE1 = false>
 __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
 {
+    static_assert(!FUSE1 || (KW == 3 && STRIDE == 1), "the fused first layer is a k = 3, stride 1 convolution");
     // input channels per LDS weight chunk: 4 x 3 taps = 12 K rows, or 16 x 1 tap -- the point-wise form would otherwise
     // meet a workgroup barrier every two k-steps (1024 -> 128, 64 positions x 256 sequences: 145 -> see DESIGN us)
     constexpr int CC = KW == 1 ? 16 : kCvCC;
@@ -109,6 +118,11 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
         s_scale[threadIdx.x] = a.scale[cs];
         s_shift[threadIdx.x] = a.shift[cs];
     }
+    constexpr int kL1Max = 128;                        // input channels the fused form takes
+    __shared__ __attribute__((aligned(16))) float s_l1[FUSE1 ? kL1Max : 1][4];
+    if (FUSE1) {
+        for (int i = threadIdx.x; i < a.Ci * 4; i += NT) (&s_l1[0][0])[i] = a.l1[i];
+    }
     const long long ncol = (long long)a.S * a.Lc;
     const long long n_g = ((long long)blockIdx.x * kCvWaves + wave) * 32 + r;   // this lane's column
     const bool col_ok = n_g < ncol;
@@ -119,6 +133,15 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
     for (int tap = 0; tap < KW; ++tap) {
         const int li = l * STRIDE + tap - kPad;                                   // input position of this tap
         tap_ok[tap] = col_ok && li >= 0 && li < a.L;
+    }
+    float xs[FUSE1 ? 5 : 1];                           // FUSE1: x[l - 2 .. l + 2] of the lane's sequence (0 outside)
+    if (FUSE1) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int q = l + j - 2;
+            xs[j] = (col_ok && q >= 0 && q < a.L) ? a.x[(long long)seq * a.L + q] : 0.0f;
+        }
+        __syncthreads();                               // s_l1 is read by the first load_x below
     }
     // 32-bit element offsets of x[seq][h][l + tap - 1] relative to the (uniform) channel row base:
     // border / tail lanes point at a valid neighbour and are zeroed after the load
@@ -182,6 +205,19 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
     float xb[2][KW][NP];
     auto load_x = [&](int set, int ci0) {
         const int cc = min(CC, a.Ci - ci0);
+        if constexpr (FUSE1) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                const int c = min(ci0 + 2 * p + h, a.Ci - 1);
+                const float4 k4 = *reinterpret_cast<const float4 *>(&s_l1[c][0]);
+#pragma unroll
+                for (int tap = 0; tap < KW; ++tap) {
+                    const float y = fmaf(k4.z, xs[tap + 2], fmaf(k4.y, xs[tap + 1], fmaf(k4.x, xs[tap], k4.w)));
+                    xb[set][tap][p] = fmaxf(y, y * a.slope1);          // LeakyReLU, 0 <= slope <= 1
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int tap = 0; tap < KW; ++tap)
 #pragma unroll
@@ -206,9 +242,16 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
         const int ci0 = ch * CC;
         const int cc = min(CC, a.Ci - ci0);
         const bool more = ch + 1 < nchunk;
+        float4 k4n[FUSE1 ? NP : 1];       // FUSE1: the next chunk's first-unit coefficients of this lane's channels
         if (more) {                       // next chunk's weights and activations are in flight during the MFMAs
             load_w(ci0 + CC);
-            load_x(SET ^ 1, ci0 + CC);
+            if constexpr (FUSE1) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p)
+                    k4n[p] = *reinterpret_cast<const float4 *>(&s_l1[min(ci0 + CC + 2 * p + h, a.Ci - 1)][0]);
+            } else {
+                load_x(SET ^ 1, ci0 + CC);
+            }
         }
         // A operand one k-step ahead of its MFMAs
         float a_cur[CT], a_nxt[CT];
@@ -227,6 +270,14 @@ __global__ __launch_bounds__(64 * kCvWaves, 4) void conv1d_kernel(ConvArgs a)
             const float bv = ok ? xb[SET][tap][p] : 0.0f;
 #pragma unroll
             for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[t], bv, acc[t], 0, 0, 0);
+            if constexpr (FUSE1) {
+                // one value of the NEXT chunk per k-step, issued behind this step's MFMAs (the matrix pipe runs them
+                // while the vector ALU does these five instructions)
+                if (more) {
+                    const float y = fmaf(k4n[p].z, xs[tap + 2], fmaf(k4n[p].y, xs[tap + 1], fmaf(k4n[p].x, xs[tap], k4n[p].w)));
+                    xb[SET ^ 1][tap][p] = fmaxf(y, y * a.slope1);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < CT; ++t) a_cur[t] = a_nxt[t];
@@ -395,19 +446,23 @@ __global__ __launch_bounds__(64 * kCvWaves, 2) void conv3_splitk_kernel(ConvArgs
 
 namespace {
 
-template <int KW, int STRIDE>
+template <int KW, int STRIDE, bool FUSE1 = false>
 void launch_conv1d(const ConvArgs &a, dim3 grid, int ct, hipStream_t s)
 {
-    if (ct == 1) conv1d_kernel<1, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
-    else if (ct == 2) conv1d_kernel<2, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
-    else conv1d_kernel<4, KW, STRIDE><<<grid, 64 * kCvWaves, 0, s>>>(a);
+    if (ct == 1) conv1d_kernel<1, KW, STRIDE, FUSE1><<<grid, 64 * kCvWaves, 0, s>>>(a);
+    else if (ct == 2) conv1d_kernel<2, KW, STRIDE, FUSE1><<<grid, 64 * kCvWaves, 0, s>>>(a);
+    else conv1d_kernel<4, KW, STRIDE, FUSE1><<<grid, 64 * kCvWaves, 0, s>>>(a);
 }
 
+// l1 != nullptr: x is the single-channel input [S][L] and the Ci input channels of this (k = 3, stride 1) convolution
+// are the first layer's outputs, computed in the kernel (ConvArgs::l1)
 int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift, int S, int Ci, int Co,
-                    int L, int kernel, int stride, int pool, double negative_slope, float *out, pof_stream_t stream)
+                    int L, int kernel, int stride, int pool, double negative_slope, float *out, pof_stream_t stream,
+                    const float *l1 = nullptr, double slope1 = 0.0)
 {
     if (!x || !wt || !scale || !shift || !out) return POF_E_BADARG;
     if (S < 0 || Ci < 1 || Co < 1 || L < 1) return POF_E_BADARG;
+    if (l1 && (kernel != 3 || stride != 1 || Ci > 128 || !(slope1 >= 0.0 && slope1 <= 1.0))) return POF_E_SHAPE;
     if (!((kernel == 3 && (stride == 1 || stride == 2)) || (kernel == 1 && stride == 1))) return POF_E_SHAPE;
     const int Lc = stride == 1 ? L : (L + 1) / 2;         // (L + 2 pad - kernel) / stride + 1 with pad = kernel / 2
     if (pool && (stride != 1 || Lc < 2 || (Lc & 1))) return POF_E_SHAPE;   // pooled pairs sit on adjacent lanes: even L
@@ -424,6 +479,8 @@ int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const f
         a.x = x + (long long)s0 * per_seq; a.wt = wt; a.scale = scale; a.shift = shift;
         a.out = out + (long long)s0 * Co * Lout;
         a.Ci = Ci; a.Co = Co; a.L = L; a.Lc = Lc; a.pool = pool ? 1 : 0; a.slope = (float)negative_slope;
+        a.l1 = l1; a.slope1 = (float)slope1;
+        if (l1) a.x = x + (long long)s0 * L;              // one input channel
         const long long ncol = (long long)a.S * Lc;
         const long long tiles = (ncol + 31) / 32;
         const long long gx = (tiles + kCvWaves - 1) / kCvWaves;
@@ -444,7 +501,7 @@ int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const f
           if (force == 1 || force == 2 || force == 4) ct = (Co <= 32 && force > 1) ? 1 : (Co <= 64 && force > 2) ? 2 : force; }
         const long long wgs = gx * ((Co + 32 * ct - 1) / (32 * ct));
         const int nchunk = (Ci + kCvCC - 1) / kCvCC;
-        if (kernel == 3 && stride == 1 && wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves &&
+        if (!l1 && kernel == 3 && stride == 1 && wgs < 2 * kCvFillWorkgroups && Ci >= Co && nchunk >= 8 * kCvWaves &&
             tiles <= 0x7fffffffLL) {
             // still a launch that leaves most SIMDs with at most one wave, and a K loop long enough to pay for
             // the reduction (Ci >= 128; measured at one scan per call: 512->256 L=7 92 -> 58 us, 256->128 L=7
@@ -456,7 +513,8 @@ int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const f
             else conv3_splitk_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
         } else {
             const dim3 grid((unsigned)gx, (Co + 32 * ct - 1) / (32 * ct));
-            if (kernel == 1) launch_conv1d<1, 1>(a, grid, ct, s);
+            if (l1) launch_conv1d<3, 1, true>(a, grid, ct, s);
+            else if (kernel == 1) launch_conv1d<1, 1>(a, grid, ct, s);
             else if (stride == 2) launch_conv1d<3, 2>(a, grid, ct, s);
             else launch_conv1d<3, 1>(a, grid, ct, s);
         }
@@ -473,6 +531,15 @@ extern "C" int pof_conv3_bn_lrelu(const float *x, const float *wt, const float *
 {
     POF_CLEAR_STALE_ERROR();
     return conv1d_bn_lrelu(x, wt, scale, shift, S, Ci, Co, L, 3, 1, pool, negative_slope, out, stream);
+}
+
+extern "C" int pof_conv3_first_two(const float *x, const float *l1, double slope1, const float *wt, const float *scale,
+                                   const float *shift, int S, int C1, int Co, int L, int pool, double negative_slope,
+                                   float *out, pof_stream_t stream)
+{
+    POF_CLEAR_STALE_ERROR();
+    if (!l1) return POF_E_BADARG;
+    return conv1d_bn_lrelu(x, wt, scale, shift, S, C1, Co, L, 3, 1, pool, negative_slope, out, stream, l1, slope1);
 }
 
 extern "C" int pof_conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const float *shift,

@@ -452,6 +452,41 @@ def conv3_bn_lrelu(x, wt, scale, shift, pool=False, negative_slope=0.1, out=None
     return out
 
 
+def conv3_first_two(x, l1, wt, scale, shift, slope1=0.1, pool=False, negative_slope=0.1, out=None):
+    """The trunk's first two units in one launch (inference): x [S,L] or [S,1,L] f32 (single-channel cutouts), l1 [C1,4]
+    f32 = the first unit as {a0, a1, a2, b} per channel (taps x folded BatchNorm scale, shift), wt [3,C1,Co] /
+    scale / shift [Co] = the second unit -> [S, Co, L//2 if pool else L]."""
+    x = _dev(x, torch.float32, "x")
+    if x.dim() == 3 and x.shape[1] == 1:
+        x = x.view(x.shape[0], x.shape[2])
+    if x.dim() != 2:
+        raise ValueError("x must be [S, L] or [S, 1, L]")
+    l1 = _dev(l1, torch.float32, "l1")
+    wt = _dev(wt, torch.float32, "wt")
+    scale = _dev(scale, torch.float32, "scale")
+    shift = _dev(shift, torch.float32, "shift")
+    S, L = x.shape
+    if l1.dim() != 2 or l1.shape[1] != 4 or l1.shape[0] > 128:
+        raise ValueError("l1 must be [C1 <= 128, 4]")
+    C1 = l1.shape[0]
+    if wt.dim() != 3 or wt.shape[0] != 3 or wt.shape[1] != C1:
+        raise ValueError("wt must be [3, C1, Co]")
+    Co = wt.shape[2]
+    if scale.numel() != Co or shift.numel() != Co:
+        raise ValueError("scale / shift must have Co entries")
+    if pool and L % 2:
+        raise ValueError("pooled output needs an even L")
+    if out is None:
+        out = torch.empty((S, Co, L // 2 if pool else L), dtype=torch.float32, device=x.device)
+    else:
+        _dev(out, torch.float32, "out")
+    if S > 0:
+        with torch.cuda.device(x.device):
+            _lib.call("pof_conv3_first_two", _ptr(x), _ptr(l1), float(slope1), _ptr(wt), _ptr(scale), _ptr(shift), S, C1, Co,
+                      L, int(bool(pool)), float(negative_slope), _ptr(out), _stream())
+    return out
+
+
 def conv1d_bn_lrelu(x, wt, scale, shift, stride=1, pool=False, negative_slope=0.1, out=None):
     """Conv1d(kernel 1 | 3, padding kernel // 2, stride 1 | 2) + folded BatchNorm + LeakyReLU [+ max_pool1d(2)] on the
     float32-MFMA implicit-GEMM kernel: x [S,Ci,L] f32, wt [kernel,Ci,Co] f32 (conv weight transposed), scale / shift

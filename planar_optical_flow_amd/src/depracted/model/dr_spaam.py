@@ -160,6 +160,10 @@ class DROW(nn.Module):
                     layers.append((conv.weight.permute(2, 1, 0).contiguous().float(), scale.float().contiguous(),
                                    shift.float().contiguous()))
                 fused[name] = layers
+            # the single-channel first unit as a per-channel table for pof_conv3_first_two: taps x scale, shift
+            wt0, sc0, sh0 = fused["conv_block_1"][0]
+            if wt0.shape[1] == 1 and wt0.shape[2] <= 128:
+                fused["first_unit_table"] = torch.cat((wt0[:, 0, :].t() * sc0[:, None], sh0[:, None]), dim=1).contiguous()
         self._fused = fused
         gate = getattr(self, "gate", None)
         if gate is not None:
@@ -173,6 +177,9 @@ class DROW(nn.Module):
             self._fused = None
         return super().train(mode)
 
+    def _slope(self, name, i):
+        return float(getattr(self, name)[i][2].negative_slope)
+
     def _run_block(self, x, name, pool):
         """One trunk block; pooled blocks pool after their last layer.  Three routes:
         eval + fuse_for_inference(): the HIP conv kernels (17 ms per B = 32 forward); eval without it on
@@ -184,8 +191,18 @@ class DROW(nn.Module):
             x = x.contiguous().float()
             layers = fused[name]
 
+            table = fused.get("first_unit_table") if name == "conv_block_1" and getattr(self, "fuse_first_unit", True) else None
+
             def run(seqs):
-                for i, (wt, scale, shift) in enumerate(layers):
+                start = 0
+                if table is not None and seqs.shape[1] == 1 and len(layers) > 1:
+                    # units 0 and 1 in one launch: the 64-channel output of the first is never written (1 GB at B = 32)
+                    wt, scale, shift = layers[1]
+                    seqs = ops.conv3_first_two(seqs, table, wt, scale, shift, slope1=self._slope(name, 0),
+                                               pool=pool and len(layers) == 2, negative_slope=self._slope(name, 1))
+                    start = 2
+                for i in range(start, len(layers)):
+                    wt, scale, shift = layers[i]
                     seqs = ops.conv3_bn_lrelu(seqs, wt, scale, shift, pool=pool and i == len(layers) - 1)
                 return seqs
             # large batches go through the block in slabs of sequences: the intermediate activations

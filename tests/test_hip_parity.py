@@ -879,6 +879,41 @@ def test_conv3_bn_lrelu_layer(ops, S, Ci, Co, L, pool):
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-4, atol=1e-5)
 
 
+@pytest.mark.parametrize("S,L,C1,Co,pool", [(72, 56, 64, 64, False), (450, 56, 64, 64, False), (33, 48, 64, 128, True),
+                                            (5, 7, 20, 33, False), (1200, 56, 64, 64, False)])
+def test_conv3_first_two_equals_two_launches(ops, S, L, C1, Co, pool):
+    """pof_conv3_first_two -- the trunk's single-channel first unit computed inside the second unit's kernel
+    (dr_spaam.py:86-92) -- against the two launches it replaces: exactly on small integers (every product and partial
+    sum is exact in float32 on both routes), to float32 round-off on random data."""
+    g = torch.Generator(device=DEV).manual_seed(S + L + C1 + Co)
+    for integers in (True, False):
+        if integers:
+            x = torch.randint(-3, 4, (S, 1, L), device=DEV, generator=g).float()
+            w0 = torch.randint(-2, 3, (3, 1, C1), device=DEV, generator=g).float()
+            sc0, sh0 = torch.ones(C1, device=DEV), torch.randint(-2, 3, (C1,), device=DEV, generator=g).float()
+            w1 = torch.randint(-2, 3, (3, C1, Co), device=DEV, generator=g).float()
+            sc1, sh1 = torch.ones(Co, device=DEV), torch.randint(-2, 3, (Co,), device=DEV, generator=g).float()
+            s0 = s1 = 0.5
+        else:
+            x = torch.randn(S, 1, L, device=DEV, generator=g)
+            w0 = torch.randn(3, 1, C1, device=DEV, generator=g) * 0.5
+            sc0, sh0 = torch.rand(C1, device=DEV, generator=g) + 0.5, torch.randn(C1, device=DEV, generator=g) * 0.2
+            w1 = torch.randn(3, C1, Co, device=DEV, generator=g) * 0.1
+            sc1, sh1 = torch.rand(Co, device=DEV, generator=g) + 0.5, torch.randn(Co, device=DEV, generator=g) * 0.2
+            s0 = s1 = 0.1
+        two = ops.conv3_bn_lrelu(ops.conv3_bn_lrelu(x, w0, sc0, sh0, negative_slope=s0), w1, sc1, sh1, pool=pool,
+                                 negative_slope=s1)
+        table = torch.cat((w0[:, 0, :].t() * sc0[:, None], sh0[:, None]), dim=1).contiguous()
+        one = ops.conv3_first_two(x, table, w1, sc1, sh1, slope1=s0, pool=pool, negative_slope=s1)
+        assert one.shape == two.shape
+        if integers:
+            assert torch.equal(one, two)
+        else:
+            assert float((one - two).abs().max()) <= 2e-5 * float(two.abs().max())
+    with pytest.raises(ValueError):
+        ops.conv3_first_two(x, table[:, :3], w1, sc1, sh1)
+
+
 @pytest.mark.parametrize("S,Ci,Co,L,K,stride", [(6, 1, 64, 450, 3, 2), (5, 64, 128, 225, 3, 2), (4, 128, 256, 113, 3, 2),
                                                  (3, 139, 128, 113, 3, 1), (2, 192, 128, 225, 3, 1), (3, 129, 2, 450, 1, 1),
                                                  (7, 3, 64, 64, 1, 1), (2, 5, 33, 9, 3, 2), (1, 2, 3, 1, 3, 2), (2, 7, 70, 2, 1, 1)])

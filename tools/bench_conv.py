@@ -40,3 +40,20 @@ for (S, Ci, Co, L, pool) in layers:
     mfma_us = -(-S * L // 32) * -(-Co // 32) * (Ci * 3 + 1) // 2 * 0.030 / 1024      # all 1024 SIMDs busy, 30 ns per 32x32x2
     print("S=%6d Ci=%3d Co=%3d L=%2d pool=%d: %7.3f ms  %6.1f TFLOP/s  %6.0f GB/s  (MFMA-issue bound %.1f us)" % (S, Ci, Co, L, pool, ms, fl / ms / 1e9, byt / ms / 1e6, mfma_us), flush=True)
 print("trunk total %.2f ms  %.1f TFLOP/s" % (tot_ms, tot_fl / tot_ms / 1e9))
+
+# the first two units in one launch (pof_conv3_first_two) against the two launches above
+if not (len(sys.argv) > 3 and sys.argv[3] == "sweep"):
+    S, L = SA, 56
+    x0 = torch.randn((S, 1, L), device="cuda")
+    table = torch.randn((64, 4), device="cuda") * 0.3
+    wt = torch.randn((3, 64, 64), device="cuda") * 0.05
+    sc = torch.ones(64, device="cuda"); sh = torch.zeros(64, device="cuda")
+    out = torch.empty((S, 64, L), device="cuda")
+    for _ in range(2): ops.conv3_first_two(x0, table, wt, sc, sh, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5): ops.conv3_first_two(x0, table, wt, sc, sh, out=out)
+    e1.record(); torch.cuda.synchronize()
+    print("S=%6d first two units fused (1 -> 64 -> 64, L=56): %7.3f ms" % (S, e0.elapsed_time(e1) / 5))
+
