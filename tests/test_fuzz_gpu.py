@@ -199,6 +199,43 @@ def test_pedestrian_only_batch_keeps_all_classes_in_the_mask(ops):
     assert n_other > 0
 
 
+def test_nms_distances_at_the_threshold(ops):
+    """Pairs of centres whose distance is min_dist up to a few float32 steps of one range -- inside the band the float32
+    screen of the wave kernel cannot decide -- and far / huge coordinates next to them: kept set and instance ids
+    equal the oracle's float64 decisions."""
+    rng = np.random.default_rng(99)
+    N, md = 450, 0.5
+    phi = R.laser_phi()
+    tab = ops.phi_table()
+    B = 64
+    scans = np.full((B, N), 25.0, np.float32)
+    reg = np.zeros((B, N, 2))
+    cls = np.tile(np.linspace(0.4, 0.1, N), (B, 1))          # distinct, low everywhere else
+    for b in range(B):
+        i = int(rng.integers(5, N - 40))
+        j = i + int(rng.integers(1, 30))
+        Rr = float(rng.uniform(1.0, 20.0))
+        dl = phi[j] - phi[i]
+        disc = md * md - (Rr * np.sin(dl)) ** 2
+        if disc <= 0:
+            continue
+        rj = Rr * np.cos(dl) + np.sqrt(disc)                 # |c_i - c_j| = min_dist
+        scans[b, i] = np.float32(Rr)
+        scans[b, j] = np.nextafter(np.float32(rj), np.float32(np.inf if b % 2 else 0.0))
+        for _ in range(b % 5):
+            scans[b, j] = np.nextafter(scans[b, j], np.float32(np.inf if b % 2 else 0.0))
+        cls[b, i], cls[b, j] = 0.9, 0.8
+        if b % 7 == 0:
+            scans[b, 3] = np.float32(3.0e6)                  # a huge coordinate widens the screen's band
+    xy, dc, num, inst = ops.nms_predicted_center(dev(scans), tab, dev(cls), dev(reg), md)
+    for b in range(B):
+        wxy, wcls, winst = R.nms_predicted_center(scans[b], phi, cls[b][:, None], reg[b], md)
+        m = int(num[b].item())
+        assert m == len(wxy), b
+        assert np.array_equal(inst[b].cpu().numpy(), winst), b
+        np.testing.assert_allclose(xy[b, :m].cpu().numpy(), wxy, rtol=0, atol=1e-9 * max(1.0, float(np.abs(wxy).max())))
+
+
 @pytest.mark.parametrize("seed", range(10 * _SCALE))
 def test_fuzz_nms_and_polar_grid(ops, seed):
     rng = np.random.default_rng(6000 + seed)
