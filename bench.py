@@ -580,7 +580,7 @@ def main():
                 result["prototype_forward"] = guarded(bench_prototype, ops, dev)
             # PMC traffic of the same shapes, read from the committed counter passes (tools/collect_profiles.sh
             # runs this very function under rocprofv3 --pmc): not measured in this run
-            for key, pref in (("cutout", ("cutout_area_kernel", "cutout_kernel<1, 7, 1,")),
+            for key, pref in (("cutout", ("cutout_area_kernel", "cutout_kernel<3, 7, 1,", "cutout_kernel<1, 7, 1,")),
                               ("spatial_attention", ("attn_",)), ("band_correlation", ("band_corr_",))):
                 tr, src = pmc_traffic(pref)
                 result[key]["roofline"]["traffic"] = tr
