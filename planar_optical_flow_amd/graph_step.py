@@ -57,7 +57,8 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, example, keys=("input", "target"), loss_fn=None, grad_norm_clip=0.0,
-                 reducer=None, warmup=3, restore=True):
+                 reducer=None, warmup=3, restore=True, keep_graph=False):
+        self._keep_graph = bool(keep_graph)      # diagnostics: the captured hipGraph_t stays reachable (raw_cuda_graph)
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a capturable optimiser (graph_step.make_capturable)")
         import torch.distributed as tdist
@@ -117,6 +118,19 @@ class GraphedTrainStep:
         self.optimizer.step()
 
     def _capture(self, warmup):
+        # Library convolutions inside a captured step must use DETERMINISTIC solvers: with MIOpen's default choice the
+        # captured module path of the box head (SyncBatchNorm ranks keep the torch modules) replayed wrong convolution
+        # gradients in about one process in ten -- a fixed 2 % deviation from the eager twin, gone in 12 of 12 runs with
+        # the flag set, unaffected by the collectives (profiles/r3_graph_capture_miopen.txt).  The solver is chosen at a
+        # shape's first call, so the warm-up steps run under the flag too.
+        prev = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = True
+        try:
+            self._capture_impl(warmup)
+        finally:
+            torch.backends.cudnn.deterministic = prev
+
+    def _capture_impl(self, warmup):
         model = self.model
         model.train()
         # warm-up on a side stream: lazy initialisations (library handles, optimiser state, gradient buffers) must not
@@ -134,7 +148,7 @@ class GraphedTrainStep:
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
         if self.reducer is None:
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=self._keep_graph)
             with torch.cuda.graph(g):
                 self.loss = self._fwd_bwd(fresh_grads=True)
                 self._update()
@@ -143,7 +157,7 @@ class GraphedTrainStep:
             # the collectives are nodes of the graph.  thread_local: the process group's watchdog thread polls
             # events while this thread captures
             self.reducer.attach()                      # gradients = views of the bucket BEFORE the capture
-            g = torch.cuda.CUDAGraph()
+            g = torch.cuda.CUDAGraph(keep_graph=self._keep_graph)
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.loss = self._fwd_bwd()
                 self.reducer.reduce_()
