@@ -699,7 +699,9 @@ def bench_box_head(dev, world, rank, backend, barrier, graph_collectives=False, 
             lmodel.backbone.hip_train = False
             lmodel.train()
             loptim = Optim(lmodel, {"scheduler_kwargs": {"epoch0": 0, "epoch1": 100, "lr0": 1e-3, "lr1": 1e-6}})
-            lstep = GraphedTrainStep(lmodel, loptim.make_capturable(), {"input": x, "target": y})
+            # (MIOpen's default solver choice: what the library path costs at its fastest -- replay-safe only with
+            # deterministic solvers, 4.3 ms; profiles/r3_graph_capture_miopen.txt)
+            lstep = GraphedTrainStep(lmodel, loptim.make_capturable(), {"input": x, "target": y}, deterministic_library=False)
             for _ in range(warm):
                 loptim.set_lr(0)
                 lstep(batch)

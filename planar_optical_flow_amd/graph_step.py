@@ -57,8 +57,9 @@ class GraphedTrainStep:
     """
 
     def __init__(self, model, optimizer, example, keys=("input", "target"), loss_fn=None, grad_norm_clip=0.0,
-                 reducer=None, warmup=3, restore=True, keep_graph=False):
+                 reducer=None, warmup=3, restore=True, keep_graph=False, deterministic_library=True):
         self._keep_graph = bool(keep_graph)      # diagnostics: the captured hipGraph_t stays reachable (raw_cuda_graph)
+        self._deterministic_library = bool(deterministic_library)
         if not all(g.get("capturable", False) for g in optimizer.param_groups):
             raise ValueError("GraphedTrainStep needs a capturable optimiser (graph_step.make_capturable)")
         import torch.distributed as tdist
@@ -122,9 +123,11 @@ class GraphedTrainStep:
         # captured module path of the box head (SyncBatchNorm ranks keep the torch modules) replayed wrong convolution
         # gradients in about one process in ten -- a fixed 2 % deviation from the eager twin, gone in 12 of 12 runs with
         # the flag set, unaffected by the collectives (profiles/r3_graph_capture_miopen.txt).  The solver is chosen at a
-        # shape's first call, so the warm-up steps run under the flag too.
+        # shape's first call, so the warm-up steps run under the flag too.  MIOpen's deterministic solvers are slow on
+        # these shapes (the box head's module path: 1.17 -> 4.3 ms per replay); ``deterministic_library=False`` keeps the
+        # default choice for measurements that accept the risk.
         prev = torch.backends.cudnn.deterministic
-        torch.backends.cudnn.deterministic = True
+        torch.backends.cudnn.deterministic = self._deterministic_library or prev
         try:
             self._capture_impl(warmup)
         finally:
