@@ -507,7 +507,10 @@ int conv1d_bn_lrelu(const float *x, const float *wt, const float *scale, const f
             // the reduction (Ci >= 128; measured at one scan per call: 512->256 L=7 92 -> 58 us, 256->128 L=7
             // 43 -> 19 us, 256->256 L=14 52 -> 45 us; the widening layers Co = 2 Ci and Ci = 64 lose 10-50 %
             // to it and keep the one-wave-per-tile form): split K over the workgroup's waves
-            const int cts = ct > 2 ? 2 : ct;                      // the partial sums go through LDS: 32 or 64 channels
+            // the partial sums go through LDS: 32 or 64 channels per workgroup.  With a very long K (Ci >= 512) the
+            // 64-channel form wins even when the 32-channel one fills more SIMDs -- two MFMAs per A-operand read
+            // instead of one over 96+ k-steps per wave (512 -> 256, L = 7, one scan: 57 -> 45 us)
+            const int cts = (ct > 2 || (nchunk >= 32 * kCvWaves && Co >= 64)) ? 2 : ct;
             const dim3 grid((unsigned)tiles, (Co + 32 * cts - 1) / (32 * cts));
             if (cts == 1) conv3_splitk_kernel<1><<<grid, 64 * kCvWaves, 0, s>>>(a);
             else conv3_splitk_kernel<2><<<grid, 64 * kCvWaves, 0, s>>>(a);
