@@ -838,6 +838,10 @@ def test_bench_single_gpu_line_and_world_size_check():
     assert cb["single_process_scans_per_s"] > 0 and cb["min"] <= cb["value"] <= cb["max"]
     assert 0 < d["host_fed"]["host_fed_scans_per_s"] < d["value"]
     assert d["box_head_train"]["grad_allreduce_ms"] is None and d["box_head_train"]["samples_per_s"] > 0
+    gr = d["box_head_train"]["graphed"]                       # configs[3] as one replay: HIP units and library modules
+    assert 0 < gr["ms_per_step"] and gr["ms_per_step_library_modules"] > 0 and d["box_head_train"]["host_syncs_per_step"] == 0
+    assert "prototype_forward" not in d                     # --no-model: the network rows are left out
+    assert d["config"]["slots_per_launch"] == 8 and d["config"]["ring_batches"] == 16
     assert d["single_batch_launches"]["ms_per_step"] >= d["ms_per_step"] * 0.95
     assert set(d["small_kernels"]) >= {"segment_kernel", "nms_kernel", "rotate_iou_kernel", "flow_errors_kernel",
                                        "gather_windows_kernel", "segment_inputs_kernel"}

@@ -145,3 +145,31 @@ def test_graphed_step_refuses_freed_gradient_buffers():
     opt.zero_grad()                               # default: gradients set to None
     with pytest.raises(RuntimeError, match="moved since the capture"):
         step(batch)
+
+
+@pytest.mark.gpu
+def test_capture_uses_deterministic_library_solvers_and_restores_the_flag():
+    """The warm-up and the capture run with deterministic library solvers (an MIOpen convolution-backward solver picked
+    by its default, timing-based choice replayed wrong gradients in about one process in ten:
+    profiles/r3_graph_capture_miopen.txt); the caller's setting is put back, and the switch can be turned off."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "planar_optical_flow_amd"))
+    from src.model.get_model import get_model
+    from planar_optical_flow_amd.graph_step import GraphedTrainStep, make_capturable
+    seen = []
+    model = get_model({"type": "box_reg", "input_dim": 3, "target_dim": 3, "dropout": 0.0}).cuda()
+    model.backbone.hip_train = False                     # library convolutions in the step
+    hook = model.backbone.conv1[0].register_forward_hook(lambda *a: seen.append(torch.backends.cudnn.deterministic))
+    batch = {"input": torch.randn(8, 64, 3, device="cuda"), "target": torch.randn(8, 3, device="cuda")}
+    for flag in (False, True):
+        torch.backends.cudnn.deterministic = flag
+        for det_lib in (True, False):
+            seen.clear()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            make_capturable(opt)
+            GraphedTrainStep(model, opt, batch, warmup=1, deterministic_library=det_lib)
+            assert seen and all(v == (det_lib or flag) for v in seen), (flag, det_lib, seen)
+            assert torch.backends.cudnn.deterministic == flag
+    torch.backends.cudnn.deterministic = False
+    hook.remove()
+
