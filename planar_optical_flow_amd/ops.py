@@ -243,7 +243,7 @@ SCAN_MAX_SLOTS = _lib.SCAN_MAX_SLOTS     # batches one launch of scan_preprocess
 
 def scan_preprocess_multi(batches, tab, next_batches=(), flow_kind=FLOW_DISPLACEMENT, canonical=True,
                           out_dtype=torch.float32, want=("flow",), assoc_radius=(0.6, 0.4, 0.35), labels=(1, 2, 3),
-                          dyn_radius=(2.5, 2.0, 2.0)):
+                          dyn_radius=(2.5, 2.0, 2.0), prepare=False):
     """A2-A7 fused for up to SCAN_MAX_SLOTS (8) batches in ONE launch (pof_scan_preprocess_multi): a loader that runs ahead hands
     over several ring slots at once.
 
@@ -252,6 +252,7 @@ def scan_preprocess_multi(batches, tab, next_batches=(), flow_kind=FLOW_DISPLACE
              `want` must be preallocated in `out`.
     next_batches: list of dict(odom0, odom1, dets, workspace) whose params this launch evaluates on extra
              workgroups.  `batches` may be empty (params only: priming the ring).
+    prepare: do not launch; return a PreparedScanLaunch that does (the arguments marshalled once).
     """
     want = set(want)
     known = {"xy", "flow", "closest", "target_cls", "target_reg", "dyn_mask", "valid_mask", "exclude_mask"}
@@ -302,10 +303,29 @@ def scan_preprocess_multi(batches, tab, next_batches=(), flow_kind=FLOW_DISPLACE
     for k, nb in enumerate(next_batches):
         nxt[k] = _scan_inputs(nb, want, flow_kind, assoc_radius, labels, dyn_radius, need_det)
     tabf = phi_table_f32(tab) if out_dtype == torch.float32 else None
+    args = (cur, len(batches), nxt, len(next_batches), N, _ptr(tab), _ptr(tabf), int(flow_kind), int(bool(canonical)),
+            int(out_dtype == torch.float64), (C.c_double * 3)(*assoc_radius), (C.c_int32 * 3)(*labels),
+            (C.c_double * 3)(*dyn_radius))
+    if prepare:
+        return PreparedScanLaunch(args, tab.device, (keep, list(next_batches), tab, tabf))
     with torch.cuda.device(tab.device):
-        _lib.call("pof_scan_preprocess_multi", cur, len(batches), nxt, len(next_batches), N, _ptr(tab), _ptr(tabf),
-                  int(flow_kind), int(bool(canonical)), int(out_dtype == torch.float64),
-                  (C.c_double * 3)(*assoc_radius), (C.c_int32 * 3)(*labels), (C.c_double * 3)(*dyn_radius), _stream())
+        _lib.call("pof_scan_preprocess_multi", *args, _stream())
+
+
+class PreparedScanLaunch:
+    """A marshalled pof_scan_preprocess_multi call (``scan_preprocess_multi(..., prepare=True)``): a loader that cycles
+    through a ring of fixed buffers builds the descriptor tables of its (current slots, next slots) combinations once
+    and then pays one ctypes call per launch -- a few microseconds of host time instead of the ~100 us the checked,
+    per-call marshalling of 8 + 8 batches costs.  The tensors it points at are kept alive by the object."""
+
+    def __init__(self, args, device, keep):
+        self._args, self._device, self._keep = args, device, keep
+        self._fn = getattr(_lib.load(), "pof_scan_preprocess_multi")
+
+    def __call__(self):
+        code = self._fn(*self._args, torch.cuda.current_stream(self._device).cuda_stream)
+        if code != _lib.POF_OK:
+            _lib.call("pof_scan_preprocess_multi", *self._args, _stream())      # the checked path raises the exception
 
 
 def flow_from_xy(xy, odom0, odom1, flow_kind=FLOW_DISPLACEMENT, canonical=False, tab=None):

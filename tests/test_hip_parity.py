@@ -1109,3 +1109,31 @@ def test_spatial_attention_backward_fused_equals_two_pass(B, N, E, F, w):
     for a, b in zip(got2[:2], ref2[:2]):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(b.abs().max()), 1.0)
     assert torch.equal(ops.spatial_attention_backward(ex, et, t, prob, go, gb, 0.5, w)[0], got[0])   # deterministic
+
+
+def test_prepared_multi_launch_equals_the_checked_call(ops):
+    """ops.scan_preprocess_multi(..., prepare=True): the marshalled launch a loader keeps per ring position gives the
+    bits of the checked call, can be issued repeatedly, and keeps its buffers alive."""
+    tab = ops.phi_table()
+    want = ("flow", "target_cls", "target_reg", "exclude_mask")
+    slots = []
+    for k in range(4):
+        sb = synth.make_batch(seed=400 + k, B=130, T=2, max_legs=6)
+        det = csr(ops, sb)
+        ws = torch.empty(ops.scan_preprocess_workspace_bytes(130, det.rphi.shape[0]), dtype=torch.uint8, device=DEV)
+        out = {"flow": torch.full((130, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "target_cls": torch.full((130, 450), -1, dtype=torch.int64, device=DEV),
+               "target_reg": torch.full((130, 450, 2), 7.0, dtype=torch.float32, device=DEV),
+               "exclude_mask": torch.full((130, 450), 7.0, dtype=torch.float32, device=DEV)}
+        slots.append({"scans": T(sb.scans), "odom0": T(sb.odom0), "odom1": T(sb.odom1), "dets": det, "workspace": ws, "out": out})
+    ref = [ops.scan_preprocess(s["scans"], tab, s["odom0"], s["odom1"], s["dets"], want=want) for s in slots]
+    prime = ops.scan_preprocess_multi([], tab, next_batches=slots[:2], want=want, prepare=True)
+    first = ops.scan_preprocess_multi(slots[:2], tab, next_batches=slots[2:], want=want, prepare=True)
+    second = ops.scan_preprocess_multi(slots[2:], tab, want=want, prepare=True)
+    assert all(torch.equal(s["out"]["flow"], torch.full_like(s["out"]["flow"], 7.0)) for s in slots)   # nothing ran yet
+    for _ in range(2):
+        prime(); first(); second()
+    torch.cuda.synchronize()
+    for k, s in enumerate(slots):
+        for name in want:
+            assert torch.equal(s["out"][name], ref[k][name]), (k, name)
