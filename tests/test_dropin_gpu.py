@@ -830,7 +830,8 @@ def test_bench_single_gpu_line_and_world_size_check():
     # ONE clock: the roofline figure is the algorithmic bytes of a step over the wall interval of ms_per_step
     assert abs(rf["achieved"] - 14400 * 4096 / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
     assert abs(rf["launch_ms"] - d["ms_per_step"] * d["steps"] / rf["launches"]) < 1e-9 and rf["steps_per_launch"] == 8
-    assert rf["events"]["ms_per_step"] <= d["ms_per_step"] * 1.02          # device interval inside the wall interval
+    # the device interval is measured on regions of its own (the wall regions hold no event records): same launches
+    assert 0.6 * d["ms_per_step"] <= rf["events"]["ms_per_step"] <= 1.3 * d["ms_per_step"]
     assert "f32" in d["dtype"] and d["value_f64"] > 0 and d["roofline_f64"]["epe_vs_oracle_m"] < 1e-12
     assert abs(d["roofline_f64"]["achieved"] - 18000 * 4096 / (d["roofline_f64"]["ms_per_step"] * 1e-3) / 1e9) < 1e-3
     cb = d["cpu_baseline"]
