@@ -307,8 +307,9 @@ def main():
             order = np.roll(np.arange(Bm), sh)
             ro = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
             rr = np.concatenate([rphi[offs[i]:offs[i + 1]] for i in order]) if len(rphi) else rphi
-            plan.append((sh, ro, rr))
-            ws_bytes[r] = ops.scan_preprocess_workspace_bytes(Bm, int(len(rr)))
+            det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
+            plan.append((sh, det))
+            ws_bytes[r] = ops.scan_preprocess_workspace_bytes(Bm, int(det.rphi.shape[0]))
         Tn = sbm.scans.shape[1]
 
         def rup(n):
@@ -327,12 +328,11 @@ def main():
             return t
         ring = []
         for r in range(a.ring):
-            sh, ro, rr = plan[r]
+            sh, det = plan[r]
             scans = carve(tuple(sbm.scans.shape), torch.float32)
             scans.copy_(torch.from_numpy(np.roll(sbm.scans, sh, axis=0)))
             o0 = torch.from_numpy(np.roll(sbm.odom0, sh, axis=0)).to(dev)
             o1 = torch.from_numpy(np.roll(sbm.odom1, sh, axis=0)).to(dev)
-            det = ops.DetCSR.from_numpy(ro, rr, np.full(len(rr), 2, np.uint8), dev)
             outs = {
                 "flow": carve((Bm, N, 2), out_dtype),
                 "target_cls": carve((Bm, N), torch.int64),
